@@ -1,0 +1,136 @@
+"""Pin the CPU oracle (oracle/assembly_oracle.py) to the reference's own outputs.
+
+The fixtures were produced by running the reference (tests/golden/tools/
+make_golden.py); these tests need neither the reference nor a GPU.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, scaled_error
+from oracle import assembly_oracle as orc
+
+TOL = 1e-14  # CPU restatement vs reference CPU run, fp64, scaled norms
+
+
+def _cells(d):
+    return d["in_vertices"][d["in_triangles"].astype(np.int64)]
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_quadrature_tables(order):
+    d = load_golden("p1_square_n8.npz")
+    nodes, weights = orc.gauss_rule(order)
+    assert np.array_equal(nodes, d[f"out_q{order}_gaussian_nodes"])
+    assert np.array_equal(weights, d[f"out_q{order}_gaussian_weights"])
+
+
+@pytest.mark.parametrize(
+    "fixture,orders",
+    [
+        ("p1_square_n8.npz", (1, 2, 3, 4)),
+        ("p1_square_n5_clockwise.npz", (3,)),
+        ("p1_delaunay_170.npz", (3,)),
+    ],
+)
+def test_p1_geometry_and_forms(fixture, orders):
+    d = load_golden(fixture)
+    conn = d["in_triangles"]
+    n = d["in_vertices"].shape[0]
+    for order in orders:
+        geo = orc.geometry(_cells(d), 1, order)
+        tag = f"out_q{order}_"
+        assert scaled_error(geo["v"], d[tag + "v"]) <= TOL
+        assert scaled_error(geo["v_grad"], d[tag + "v_grad"]) <= TOL
+        assert scaled_error(geo["integration_points"], d[tag + "integration_points"]) <= TOL
+        assert scaled_error(geo["dx"], d[tag + "dx"]) <= TOL
+        assert scaled_error(geo["inv_map_jacobian"], d[tag + "inv_map_jacobian"]) <= TOL
+        for name, integrand in (
+            ("K_stiffness", orc.integrand_stiffness(geo)),
+            ("K_stiffness_mass", orc.integrand_stiffness_mass(geo)),
+            ("K_mass", orc.integrand_mass(geo)),
+            ("K_convection_x", geo["v"] @ np.swapaxes(geo["v_grad"][..., [0]], -1, -2)),
+        ):
+            local = orc.integrate_local(integrand, geo["dx"])
+            dense = orc.assemble_dense_bilinear(local, conn, n)
+            assert scaled_error(dense, d[tag + name]) <= TOL, name
+            rowptr, colind, slots = orc.csr_pattern(conn, n)
+            vals = orc.assemble_csr_values(local, slots, colind.shape[0])
+            assert scaled_error(orc.csr_to_dense(rowptr, colind, vals, n), d[tag + name]) <= TOL
+        f = orc.assemble_linear(orc.integrate_local(orc.integrand_load(geo), geo["dx"]), conn, n)
+        assert scaled_error(f, d[tag + "f_load"]) <= TOL
+        fun = orc.integrate_functional(orc.source_sin_sin(geo["integration_points"]) ** 2, geo["dx"])
+        assert scaled_error(fun, d[tag + "functional_rhs2"]) <= TOL
+
+
+def test_signed_determinant_is_kept():
+    d = load_golden("p1_square_n5_clockwise.npz")
+    geo = orc.geometry(_cells(d), 1, 3)
+    assert (geo["det"] < 0).any() and (geo["det"] > 0).any()
+
+
+def test_float32_path():
+    d = load_golden("p1_square_n6_float32.npz")
+    cells = d["in_vertices"].astype(np.float32)[d["in_triangles"].astype(np.int64)]
+    geo = orc.geometry(cells, 1, 4)
+    assert geo["v_grad"].dtype == np.float32
+    assert scaled_error(geo["v_grad"], d["out_q4_v_grad"]) <= 1e-6
+    local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+    dense = orc.assemble_dense_bilinear(local, d["in_triangles"], d["in_vertices"].shape[0])
+    assert scaled_error(dense, d["out_q4_K_stiffness"]) <= 1e-5
+
+
+def test_closed_form_stiffness_matches_reference_output():
+    d = load_golden("p1_square_n8.npz")
+    k = orc.p1_stiffness_closed_form(d["in_vertices"], d["in_triangles"])
+    dense = orc.assemble_dense_bilinear(k, d["in_triangles"], d["in_vertices"].shape[0])
+    assert scaled_error(dense, d["out_q3_K_stiffness"]) <= 1e-13
+
+
+@pytest.mark.parametrize("order", [2, 3, 4])
+def test_p2_element_level(order):
+    d = load_golden("p2_element.npz")
+    geo = orc.geometry(d["in_cell_coordinates"], 2, order)
+    tag = f"out_q{order}_"
+    assert scaled_error(geo["v"], d[tag + "v"]) <= TOL
+    assert scaled_error(geo["v_grad"], d[tag + "v_grad"]) <= TOL
+    assert scaled_error(geo["dx"], d[tag + "dx"]) <= TOL
+    k = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+    m = orc.integrate_local(orc.integrand_mass(geo), geo["dx"])
+    assert scaled_error(k, d[tag + "local_stiffness"]) <= TOL
+    assert scaled_error(m, d[tag + "local_mass"]) <= TOL
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_p2_global(order):
+    d = load_golden("p2_global_n4.npz")
+    conn6 = d["in_p2_connectivity"]
+    n = int(conn6.max()) + 1
+    geo = orc.geometry(_cells(d), 2, order)
+    tag = f"out_q{order}_"
+    k = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+    assert scaled_error(orc.assemble_dense_bilinear(k, conn6, n), d[tag + "K_stiffness"]) <= TOL
+    km = orc.integrate_local(orc.integrand_stiffness_mass(geo), geo["dx"])
+    assert scaled_error(orc.assemble_dense_bilinear(km, conn6, n), d[tag + "K_stiffness_mass"]) <= TOL
+    f = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
+    assert scaled_error(orc.assemble_linear(f, conn6, n), d[tag + "f_load"]) <= TOL
+
+
+@pytest.mark.parametrize("fixture", ["fracture_L4.npz", "fracture_L3_jitter.npz"])
+def test_fracture_geometry_and_assembly(fixture):
+    d = load_golden(fixture)
+    verts = np.stack([d["in_vertices"]] * 2)
+    tris = d["in_triangles"].astype(np.int64)
+    fmap = orc.fracture_map(verts, d["in_fractures_3d"])
+    assert scaled_error(fmap["jacobian"], d["out_mesh_jacobian_fracture_map"]) <= TOL
+    assert scaled_error(fmap["pinv"], d["out_mesh_inv_jacobian_fracture_map"]) <= TOL
+    assert scaled_error(fmap["det"], d["out_mesh_det_jacobian_fracture_map"]) <= TOL
+    cells = verts[:, tris]
+    geo = orc.fracture_geometry(cells, fmap, 4)
+    assert scaled_error(geo["v_grad"], d["out_frac_v_grad"]) <= TOL
+    assert scaled_error(geo["dx"], d["out_frac_dx"]) <= TOL
+    assert scaled_error(geo["integration_points"], d["out_frac_integration_points"]) <= TOL
+    conn = d["out_gt_triangles"]
+    n = d["out_gt_vertices_2D"].shape[0]
+    k = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"]).reshape(-1, 3, 3)
+    assert scaled_error(orc.assemble_dense_bilinear(k, conn, n), d["out_A"]) <= TOL
