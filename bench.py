@@ -1,0 +1,208 @@
+"""Benchmark of the assembly hot path: Melements/s assembled (global K + f).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one mesh: P1 stiffness operator K (CSR values)
+and load vector f, integration order 3, fp64, from vertex coordinates + connectivity
+resident in HBM.  Workload at N = 1: mesh S(2236, 0.25, 0) = 9,999,392 elements (the
+10 M-element mesh BASELINE.json's target is quoted on).  For N > 1 every rank holds one
+such mesh strip of a [0,N]x[0,1] domain (weak scaling) and the shared-DoF rows are
+exchanged with an RCCL all-reduce (pytorch_fem_solver_amd/parallel.py).
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
+    p.add_argument("--order", type=int, default=3, help="integration order")
+    p.add_argument("--cpu-sample", type=int, default=707, help="n of the CPU-baseline sample mesh")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--kernel", default="auto", help="auto | atomic | tiles")
+    return p.parse_args()
+
+
+def algorithmic_bytes(n_elems, n_verts, nnz):
+    """conn 12 B/elem + each vertex once 16 B + each CSR value once 8 B."""
+    return 12 * n_elems + 16 * n_verts + 8 * nnz
+
+
+def cpu_baseline(n, order):
+    """The numpy oracle (a port of the reference's op sequence) timed on this host:
+    geometry + local K + local f + scatter into CSR values / vector."""
+    from oracle import assembly_oracle as orc
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh = meshgen.unit_square(n, 0.25, 0)
+    verts, tris = mesh["vertices"], mesh["triangles"]
+    nv = verts.shape[0]
+    rowptr, colind, slots = orc.csr_pattern(tris, nv)  # symbolic, not timed (as on the GPU)
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        cells = verts[tris.astype(np.int64)]
+        geo = orc.geometry(cells, 1, order)
+        k_local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+        f_local = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
+        vals = np.bincount(slots.reshape(-1), weights=k_local.reshape(-1), minlength=colind.shape[0])
+        f = np.bincount(tris.reshape(-1), weights=f_local.reshape(-1), minlength=nv)
+        best = min(best, time.perf_counter() - t0)
+    del vals, f
+    n_elems = tris.shape[0]
+    return {
+        "value": n_elems / best / 1e6,
+        "unit": "Melements/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order}, numpy oracle, best of 2",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import pytorch_fem_solver_amd as tf
+    from pytorch_fem_solver_amd import meshgen, parallel
+
+    torch.set_default_dtype(torch.float64)
+    n = args.n
+    # rank r owns the strip [r, r+1] x [0, 1]; identical jitter pattern per strip so that
+    # the shared boundary column coincides (boundary vertices are never displaced)
+    mesh_np = meshgen.structured_rectangle(n, n, float(rank), float(rank + 1), 0.0, 1.0, jitter=0.25, seed=0)
+    n_elems = mesh_np["triangles"].shape[0]
+    n_verts = mesh_np["vertices"].shape[0]
+
+    torch.set_default_device(device)
+    mesh = tf.MeshTri(triangulation=mesh_np)
+    basis = tf.Basis(mesh, tf.ElementTri(polynomial_order=1, integration_order=args.order))
+    engine = basis._engine
+    _, colind, _ = engine.csr_structure()
+    nnz = int(colind.shape[0])
+    nq = engine.n_quad
+
+    # source values at the integration points: the user's f(x_q), evaluated by torch once
+    # (tests/test_assembly.py:75-84); the per-step hot path consumes them from HBM
+    import math
+
+    pts = engine.geometry()[2]
+    fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
+    del pts
+
+    exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine) if distributed else None
+
+    def step():
+        vals = engine.bilinear(1.0, 0.0)
+        f = engine.load(fq)
+        if exchange is not None:
+            exchange.reduce(vals, f)
+        return vals, f
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        vals = engine.bilinear(1.0, 0.0)
+        ends[i].record()
+        f = engine.load(fq)
+        if exchange is not None:
+            exchange.reduce(vals, f)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+
+    if rank == 0:
+        total_elems = n_elems * world
+        ms_per_step = elapsed * 1e3 / args.steps
+        algo = algorithmic_bytes(n_elems, n_verts, nnz)
+        achieved = algo / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Melements/s assembled (global K + f)",
+            "value": total_elems / (elapsed / args.steps) / 1e6,
+            "unit": "Melements/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"P1 Poisson stiffness K (CSR) + load f, order {args.order}, "
+                f"mesh S({n},0.25,0) per GPU = {n_elems} elements, {n_verts} DoFs, nnz {nnz}",
+                "elements_per_gpu": n_elems,
+                "partition": "one unit-square strip per rank" if world > 1 else "single mesh",
+                "kernel": engine.kernel_name(),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": engine.kernel_name(),
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo,
+                "kernel_ms": k_ms,
+            },
+        }
+        if not args.no_cpu_baseline:
+            torch.set_default_device("cpu")
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.order)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * tfem_assembly.h -- C ABI of the MI355X (gfx950) element-wise FEM assembly path.
+ *
+ * Drop-in boundary for the hot path of Nicolas-Zamorano/pytorch_fem_solver
+ * (package torch_fem).  The reference has no FFI: the path is a sequence of
+ * torch tensor expressions inside AbstractBasis (torch_fem/basis/
+ * abstract_basis.py:42-112).  Each entry point below names the reference
+ * lines it replaces.  All signatures are plain pointers and sizes: no torch
+ * types cross this boundary.
+ *
+ * Conventions
+ *   - "device" pointers are HIP device pointers valid on the current device;
+ *     "host" pointers are ordinary process memory.  The library never
+ *     allocates or frees caller-visible memory and keeps no global state.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Device entry points only enqueue work; they never synchronise.
+ *   - every function returns a tfem_status (0 = success).  tfem_last_error()
+ *     returns a thread-local human-readable message for the last failure.
+ *   - connectivity is row-major (n_elems, n_local) with 4- or 8-byte signed
+ *     indices (`idx_bytes`), as the reference keeps it (int32 from MeshTri,
+ *     abstract_mesh.py:51-54; int64 from FractureBasis, fracture_basis.py:80).
+ *   - real type: `real_bytes` 8 = double (the graded path), 4 = float.
+ *   - scatter convention (reference basis.py:73-76 + abstract_basis.py:166-167):
+ *     local[i][j] is ADDED to A[conn[e][j]][conn[e][i]].
+ *   - quadrature: `quad_order` 1..4 selects the 1/3/4/6-point triangle rule
+ *     with the literals of element_tri.py:77-130.
+ */
+#ifndef TFEM_ASSEMBLY_H
+#define TFEM_ASSEMBLY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFEM_ABI_VERSION 1
+
+typedef enum tfem_status {
+  TFEM_OK = 0,
+  TFEM_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, negative size, bad idx_bytes ... */
+  TFEM_ERR_UNSUPPORTED = 2,      /* quadrature / polynomial order the reference raises on */
+  TFEM_ERR_HIP = 3,              /* a HIP runtime call failed */
+  TFEM_ERR_INDEX_RANGE = 4,      /* connectivity entry outside [0, n_dofs) or nnz >= 2^31 */
+  TFEM_ERR_NO_DEVICE = 5         /* no gfx950 device visible */
+} tfem_status;
+
+int tfem_abi_version(void);
+const char *tfem_status_string(int status);
+const char *tfem_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int tfem_device_count(void);
+/* Number of quadrature points of `quad_order` (1,3,4,6), or 0 if unsupported.
+ * Replaces the shape of ElementTri._compute_gauss_values (element_tri.py:77-130). */
+int tfem_quadrature_size(int quad_order);
+/* Copy the rule: nodes (Q,2) and weights (Q) as doubles (host pointers). */
+int tfem_quadrature_rule(int quad_order, double *nodes_host, double *weights_host);
+
+/* ------------------------------------------------------------------------- *
+ * Symbolic phase (HOST memory, once per mesh).
+ * Replaces Basis._compute_basis_parameters (basis.py:64-85): instead of the
+ * 2 x (n^2 N_T) index tensors for a dense index_put_, it produces the CSR
+ * pattern of the operator and, per element entry, the CSR position it adds to.
+ * ------------------------------------------------------------------------- */
+
+/* Pass 1: rowptr_host[n_dofs+1] (int64) and *nnz_host. */
+int tfem_csr_symbolic_count(const void *conn_host, int idx_bytes, int64_t n_elems,
+                            int n_local, int64_t n_dofs, int64_t *rowptr_host,
+                            int64_t *nnz_host);
+/* Pass 2: colind_host[nnz] (int32, ascending inside each row) and
+ * slots_host[n_elems*n_local*n_local] (int32): slots[e][i][j] = CSR position of
+ * (row conn[e][j], col conn[e][i]).  `rowptr_host` is the output of pass 1. */
+int tfem_csr_symbolic_fill(const void *conn_host, int idx_bytes, int64_t n_elems,
+                           int n_local, int64_t n_dofs, const int64_t *rowptr_host,
+                           int32_t *colind_host, int32_t *slots_host);
+
+/* ------------------------------------------------------------------------- *
+ * Geometry cache (DEVICE).  Replaces AbstractBasis._compute_integral_values
+ * (abstract_basis.py:42-63) with Basis._compute_jacobian_map /
+ * _compute_integration_points / _compute_integral_weights (basis.py:87-96) and
+ * ElementTri.compute_det_and_inv_map / compute_shape_functions
+ * (element_tri.py:28-75,132-145), fused with the X[conn] gather
+ * (abstract_mesh.py:257-262).  Any output pointer may be NULL (skipped).
+ *   coords   (n_verts, 2)            conn (n_elems, 3) vertex ids
+ *   v_grad   P1: (n_elems, 3, 2)     P2: (n_elems, Q, 6, 2)
+ *   dx       (n_elems, Q)            = 0.5 * w_q * det   (signed det)
+ *   points   (n_elems, Q, 2)         inv_jac (n_elems, 2, 2)
+ * ------------------------------------------------------------------------- */
+int tfem_tri_geometry(const void *coords, int real_bytes, const void *conn, int idx_bytes,
+                      int64_t n_elems, int64_t n_verts, int poly_order, int quad_order,
+                      void *v_grad, void *dx, void *points, void *inv_jac, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fused bilinear forms (DEVICE): alpha * grad(u).grad(v) + beta * u v,
+ * i.e. the integrands `v_grad @ v_grad.mT`, `v @ v.mT` and their sum
+ * (tests/test_assembly.py:68-73, examples/example_fractures_fem.py:112-116),
+ * integrated as abstract_basis.py:83 and scattered as :87-91, gather fused.
+ *   conn_geo  (n_elems, 3) vertex ids into coords (geometry)
+ *   slots     (n_elems, n, n) from tfem_csr_symbolic_fill, n = 3 (P1) or 6 (P2)
+ *   vals      (nnz) CSR values; OVERWRITTEN (zero-filled by this call, then summed)
+ * Fracture variant (fracture_basis.py:20-26,189-197): if `frac_pinv` is not NULL
+ * the elements are `n_fractures` consecutive groups of n_elems/n_fractures; the
+ * reference gradients are post-multiplied by frac_pinv[f] (2x3) and dx by
+ * frac_det[f].
+ * ------------------------------------------------------------------------- */
+int tfem_tri_bilinear_csr(const void *coords, int real_bytes, const void *conn_geo,
+                          int idx_bytes, int64_t n_elems, int64_t n_verts, int poly_order,
+                          int quad_order, double alpha, double beta, const int32_t *slots,
+                          void *vals, int64_t nnz, const void *frac_pinv,
+                          const void *frac_det, int n_fractures, int64_t coords_per_fracture,
+                          void *stream);
+
+/* Fused linear form f(x_q) * v (tests/test_assembly.py:79-84): `fq` (n_elems, Q) are
+ * the user's source values at the integration points.  out (n_dofs) is overwritten.
+ * conn_dof (n_elems, n) are the global DoF ids (P1: n = 3, may equal conn_geo). */
+int tfem_tri_load_vector(const void *coords, int real_bytes, const void *conn_geo,
+                         const void *conn_dof, int idx_bytes, int64_t n_elems,
+                         int64_t n_verts, int poly_order, int quad_order, const void *fq,
+                         void *out, int64_t n_dofs, const void *frac_det, int n_fractures,
+                         int64_t coords_per_fracture, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Generic quadrature-reduce + scatter (DEVICE) for integrands torch evaluated
+ * from an arbitrary user callable.  integrand is (n_elems, Q, n, m) addressed by
+ * element strides `es`,`qs` (in elements of the real type; 0 = broadcast) with
+ * the inner (n, m) block contiguous.  Computes sum_q integrand * dx exactly as
+ * abstract_basis.py:83 / :104 / :72 and
+ *   bilinear  (m = n): adds into CSR vals through `slots`      (:87-91)
+ *   linear    (m = 1): adds into out[conn_dof]                 (:106-110)
+ *   functional(m = 1): writes out[e] = sum_k sum_q (n_inner = n, usually 1)  (:65-72)
+ * `vals` / `out` are overwritten.
+ * ------------------------------------------------------------------------- */
+int tfem_reduce_scatter_bilinear(const void *integrand, int real_bytes, int64_t es, int64_t qs,
+                                 const void *dx, int64_t n_elems, int n_quad, int n_local,
+                                 const int32_t *slots, void *vals, int64_t nnz, void *stream);
+int tfem_reduce_scatter_linear(const void *integrand, int real_bytes, int64_t es, int64_t qs,
+                               const void *dx, int64_t n_elems, int n_quad, int n_local,
+                               const void *conn_dof, int idx_bytes, void *out, int64_t n_dofs,
+                               void *stream);
+int tfem_reduce_functional(const void *integrand, int real_bytes, int64_t es, int64_t qs,
+                           const void *dx, int64_t n_elems, int n_quad, int n_inner, void *out,
+                           void *stream);
+
+/* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
+ * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
+int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,
+                      int real_bytes, int64_t n_dofs, void *dense, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFEM_ASSEMBLY_H */

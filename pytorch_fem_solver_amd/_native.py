@@ -1,0 +1,118 @@
+"""ctypes binding of libtfem_hip.so (include/tfem_assembly.h).
+
+There is deliberately no fallback: if the library is missing, or a hot-path call is
+made without a GPU, this module raises.  The assembly path of this package IS the HIP
+library.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtfem_hip.so")
+
+_lib = None
+
+#: every symbol include/tfem_assembly.h declares -> (restype, argtypes)
+SIGNATURES = {
+    "tfem_abi_version": (c_int, []),
+    "tfem_status_string": (c_char_p, [c_int]),
+    "tfem_last_error": (c_char_p, []),
+    "tfem_device_count": (c_int, []),
+    "tfem_quadrature_size": (c_int, [c_int]),
+    "tfem_quadrature_rule": (c_int, [c_int, c_void_p, c_void_p]),
+    "tfem_csr_symbolic_count": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p],
+    ),
+    "tfem_csr_symbolic_fill": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
+    "tfem_tri_geometry": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_int]
+        + [c_void_p] * 5,
+    ),
+    "tfem_tri_bilinear_csr": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_double, c_double,
+         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_void_p],
+    ),
+    "tfem_tri_load_vector": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p,
+         c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p],
+    ),
+    "tfem_reduce_scatter_bilinear": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+         c_int64, c_void_p],
+    ),
+    "tfem_reduce_scatter_linear": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
+         c_void_p, c_int64, c_void_p],
+    ),
+    "tfem_reduce_functional": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "tfem_csr_to_dense": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p],
+    ),
+}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtfem_hip.so (once).  Raises NativeLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: the HIP assembly library is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repository root. "
+            "There is no CPU fallback for the assembly path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, surface it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.tfem_abi_version() != 1:
+        raise NativeLibraryMissing(f"ABI version {lib.tfem_abi_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    """Map a tfem_status to the exception the reference would raise at that point."""
+    if status == 0:
+        return
+    lib = load()
+    message = lib.tfem_last_error().decode() or lib.tfem_status_string(status).decode()
+    if status == 2:  # TFEM_ERR_UNSUPPORTED <-> the reference's NotImplementedError sites
+        raise NotImplementedError(message)
+    if status in (1, 4):
+        raise ValueError(message)
+    raise RuntimeError(f"libtfem_hip: {message}")
+
+
+def ptr(tensor):
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if tensor is None else c_void_p(tensor.data_ptr())
+
+
+def current_stream(device):
+    import torch
+
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,210 @@
+"""``AbstractBasis``: the reference's integration API on top of the HIP assembly path.
+
+Mirror of reference torch_fem/basis/abstract_basis.py.  What the reference does with a
+chain of torch expressions per call -- geometry at quadrature points (:42-63),
+``(integrand * dx).sum(-3)`` (:83,:104,:72) and ``index_put_(accumulate=True)`` into a
+dense target (:81-91,:102-110) -- happens here inside libtfem_hip (csrc/), for tensors
+on the GPU directly and for CPU tensors by staging through the GPU.  No torch
+implementation of those steps exists in this class.
+"""
+
+from __future__ import annotations
+
+import abc
+import os
+
+import torch
+
+from ..sparse import CSRMatrix
+from . import forms
+
+#: above this many bytes the dense (N, N) layout of the reference is not materialised
+DENSE_LIMIT_BYTES = int(os.environ.get("TORCH_FEM_DENSE_LIMIT_BYTES", str(4 << 30)))
+
+
+class _LinearFormFunction(torch.autograd.Function):
+    """Differentiable quadrature-reduce + scatter (the VPINN training step differentiates
+    through integrate_linear_form, reference examples/example_weak.py:132-152)."""
+
+    @staticmethod
+    def forward(ctx, integrand, basis):
+        ctx.basis = basis
+        ctx.in_shape = integrand.shape
+        return basis._engine.reduce_linear(integrand.detach(), basis._dx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        basis = ctx.basis
+        conn = basis._engine._inputs()["conn_dof"].long()
+        dx = basis._dx.to(grad_out.device)
+        lead = tuple(dx.shape[:-3])
+        g = grad_out.reshape(-1)[conn].reshape(lead + (1, conn.shape[-1], 1))
+        grad_integrand = g * dx
+        return grad_integrand.sum_to_size(ctx.in_shape), None
+
+
+class AbstractBasis(abc.ABC):
+    """Finite-element basis on a mesh (abstract_basis.py:10-40)."""
+
+    #: geometry attributes computed on first access by one tfem_tri_geometry launch
+    _LAZY = ("v_grad", "integration_points", "_dx", "_inv_map_jacobian")
+
+    def __init__(self, mesh, element):
+        self._element = element
+        self.mesh = mesh
+        self._geometry_cache = {}
+        (
+            self._coords4global_dofs,
+            self._global_dofs4elements,
+            self._nodes4boundary_dofs,
+            self._coords4elements,
+        ) = self._compute_dofs(mesh, element)
+        self._basis_parameters = self._compute_basis_parameters(
+            self._coords4global_dofs, self._global_dofs4elements, self._nodes4boundary_dofs
+        )
+        self._engine = self._make_engine(mesh, element)
+        self.v = self._compute_shape_values(element)
+
+    # ---- lazily materialised geometry cache (abstract_basis.py:42-63) -------------
+    def __getattr__(self, name):
+        if name in AbstractBasis._LAZY:
+            cache = self.__dict__.get("_geometry_cache")
+            if cache is None:
+                raise AttributeError(name)
+            if name not in cache:
+                cache.update(self._compute_integral_values(self.mesh, self._element))
+            return cache[name]
+        raise AttributeError(f"{type(self).__name__!s} has no attribute {name!r}")
+
+    def __setattr__(self, name, value):
+        if name in AbstractBasis._LAZY:
+            self._geometry_cache[name] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    def _compute_shape_values(self, element):
+        bar = element.compute_barycentric_coordinates(element.gaussian_nodes)
+        v, _ = element.compute_shape_functions(
+            bar, torch.zeros((1, 1, 2, 2), dtype=bar.dtype, device=bar.device)
+        )
+        return v
+
+    @abc.abstractmethod
+    def _make_engine(self, mesh, element):
+        ...
+
+    @abc.abstractmethod
+    def _compute_integral_values(self, mesh, element) -> dict:
+        """Return {'v_grad','integration_points','_dx','_inv_map_jacobian'} in the
+        reference's shapes."""
+
+    @abc.abstractmethod
+    def _compute_dofs(self, mesh, element):
+        ...
+
+    @abc.abstractmethod
+    def _compute_basis_parameters(self, coords4global_dofs, global_dofs4elements, nodes4boundary_dofs):
+        ...
+
+    # ---- integration API ---------------------------------------------------------------
+    def integrate_functional(self, function, *args, **kwargs):
+        """Per-element integral of ``function(basis, ...)`` (abstract_basis.py:65-72)."""
+        integrand = function(self, *args, **kwargs)
+        out = self._engine.reduce_functional(integrand, self._dx)
+        return self._engine._home(out)
+
+    def integrate_bilinear_form(self, function, *args, layout=None, **kwargs):
+        """Global operator of a bilinear form (abstract_basis.py:74-93).
+
+        ``layout``: "dense" (the reference's (N, N) tensor), "csr" (``CSRMatrix``) or None
+        = dense while it fits ``DENSE_LIMIT_BYTES``, CSR beyond.
+        """
+        expr = forms.trace(function, self, args, kwargs)
+        if isinstance(expr, forms.BilinearExpr):
+            vals = self._engine.bilinear(expr.alpha, expr.beta)
+        else:
+            integrand = function(self, *args, **kwargs)
+            vals = self._engine.reduce_bilinear(integrand, self._dx)
+        matrix = self._engine.wrap_csr(vals)
+        n = matrix.shape[0]
+        if layout is None:
+            layout = "dense" if n * n * vals.element_size() <= DENSE_LIMIT_BYTES else "csr"
+        if layout == "csr":
+            return matrix if matrix.device == self._engine.home else matrix.to(self._engine.home)
+        if layout != "dense":
+            raise ValueError(f"unknown layout {layout!r}")
+        return self._engine._home(matrix.to_dense())
+
+    def integrate_linear_form(self, function, *args, **kwargs):
+        """Global vector of a linear form, shape (N, 1) (abstract_basis.py:95-112)."""
+        expr = forms.trace(function, self, args, kwargs)
+        if isinstance(expr, forms.LinearExpr) and not expr.coefficient.requires_grad:
+            coefficient = self._source_values(expr.coefficient)
+            if coefficient is not None:
+                return self._engine._home(self._engine.load(coefficient)).reshape(-1, 1)
+        integrand = function(self, *args, **kwargs)
+        if integrand.requires_grad:
+            out = _LinearFormFunction.apply(integrand, self)
+        else:
+            out = self._engine.reduce_linear(integrand, self._dx)
+        return self._engine._home(out).reshape(-1, 1)
+
+    def _source_values(self, coefficient):
+        """(E, Q) source values if ``coefficient`` broadcasts to (..., Q, 1, 1), else None."""
+        lead = tuple(self._engine.lead_shape)
+        want = lead + (self._engine.n_quad, 1, 1)
+        try:
+            full = torch.broadcast_shapes(tuple(coefficient.shape), want)
+        except RuntimeError:
+            return None
+        if tuple(full) != want:
+            return None
+        return coefficient.expand(want).reshape(-1, self._engine.n_quad)
+
+    def reduce(self, tensor):
+        """Restrict to interior DoFs (abstract_basis.py:114-117)."""
+        idx = self._basis_parameters["inner_dofs"]
+        if isinstance(tensor, CSRMatrix):
+            tensor = tensor.to_dense()
+        return tensor[idx, :][:, idx] if tensor.size(-1) != 1 else tensor[idx]
+
+    def reshape_for_assembly(self, local_matrices, form):
+        """abstract_basis.py:162-171"""
+        if form == "bilinear":
+            return local_matrices.reshape(-1)
+        if form == "linear":
+            return local_matrices.reshape(-1, 1)
+        raise NotImplementedError(f"Unknown form type: {format(form)}")
+
+    def solution_tensor(self):
+        """Zero vector (N, 1) (abstract_basis.py:173-175)."""
+        return torch.zeros(self._basis_parameters["linear_form_shape"])
+
+    def solve(self, matrix, solution, vector, only_inner_dofs=True):
+        """Dense solve on the interior DoFs (abstract_basis.py:177-195); out of the
+        assembly kernel's scope."""
+        if only_inner_dofs is True:
+            matrix = self.reduce(matrix)
+            vector = self.reduce(vector)
+        elif isinstance(matrix, CSRMatrix):
+            matrix = matrix.to_dense()
+        solution[self._basis_parameters["inner_dofs"]] += torch.linalg.solve(matrix, vector)
+        return solution
+
+
+class LazyIndexDict(dict):
+    """``_basis_parameters`` with the 2 x (n^2 N_T) dense scatter indices of the reference
+    (basis.py:73-76) built only if somebody asks for them."""
+
+    def __init__(self, *args, connectivity=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._connectivity = connectivity
+
+    def __missing__(self, key):
+        if key != "bilinear_form_idx":
+            raise KeyError(key)
+        conn = self._connectivity.reshape(-1, self._connectivity.shape[-1])
+        n = conn.shape[-1]
+        value = (conn.repeat(1, n).reshape(-1), conn.repeat_interleave(n).reshape(-1))
+        self[key] = value
+        return value

@@ -1,0 +1,115 @@
+"""``Basis``: H1-conforming Lagrange basis on one 2-D triangle mesh.
+
+Mirror of reference torch_fem/basis/basis.py.  P1 as in the reference (DoFs = vertices,
+basis.py:22-24).  P2 is an extension: the reference has the shape functions
+(element_tri.py:43-70) but raises in ``_compute_dofs`` (basis.py:50-51); here the edge
+DoFs are numbered ``N_v + edge_id`` as its commented-out block intends (dofs.py).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import dofs
+from .base import AbstractBasis, LazyIndexDict
+from .engine import AssemblyEngine
+
+
+class Basis(AbstractBasis):
+    def _compute_dofs(self, mesh, element):
+        if element.polynomial_order == 1:
+            coords = mesh["vertices", "coordinates"]
+            conn = mesh["cells", "vertices"]
+            markers = mesh["vertices", "markers"]
+            return coords, conn, markers, mesh["cells", "coordinates"]
+        if element.polynomial_order == 2:
+            conn6, xy, markers = dofs.p2_dofs_numpy(
+                mesh["vertices", "coordinates"].cpu().numpy(),
+                mesh["cells", "vertices"].cpu().numpy(),
+                mesh["edges", "vertices"].cpu().numpy(),
+                mesh["edges", "markers"].cpu().numpy(),
+                mesh["vertices", "markers"].cpu().numpy(),
+            )
+            coords = torch.tensor(xy, dtype=mesh["vertices", "coordinates"].dtype)
+            conn = torch.tensor(conn6, dtype=torch.int32)
+            return coords, conn, torch.tensor(markers, dtype=torch.int32), coords[conn]
+        raise NotImplementedError("Polynomial order not implemented")
+
+    def _compute_basis_parameters(self, coords4global_dofs, global_dofs4elements, nodes4boundary_dofs):
+        nb_global_dofs = coords4global_dofs.size(-2)
+        inner_dofs = torch.nonzero(nodes4boundary_dofs != 1, as_tuple=True)[-2]
+        return LazyIndexDict(
+            {
+                "bilinear_form_shape": (nb_global_dofs, nb_global_dofs),
+                "linear_form_shape": (nb_global_dofs, 1),
+                "linear_form_idx": (global_dofs4elements.reshape(-1),),
+                "inner_dofs": inner_dofs,
+                "nb_dofs": nb_global_dofs,
+            },
+            connectivity=global_dofs4elements,
+        )
+
+    def _make_engine(self, mesh, element):
+        return AssemblyEngine(
+            mesh["vertices", "coordinates"],
+            mesh["cells", "vertices"],
+            self._global_dofs4elements,
+            self._basis_parameters["nb_dofs"],
+            element.polynomial_order,
+            element.integration_order,
+        )
+
+    def _compute_integral_values(self, mesh, element):
+        """One tfem_tri_geometry launch; reshaped to the reference's layouts
+        (abstract_basis.py:42-63; shapes in SURVEY.md appendix A)."""
+        eng = self._engine
+        v_grad, dx, points, inv = eng.geometry()
+        e, q = eng.n_elems, eng.n_quad
+        v_grad = v_grad.reshape(e, 1, 3, 2) if eng.poly_order == 1 else v_grad
+        return {
+            "v_grad": eng._home(v_grad),
+            "integration_points": eng._home(points.reshape(e, q, 1, 2)),
+            "_dx": eng._home(dx.reshape(e, q, 1, 1)),
+            "_inv_map_jacobian": eng._home(inv.reshape(e, 1, 2, 2)),
+        }
+
+    # kept for API parity; the fused kernels do not call them
+    def _compute_jacobian_map(self, mesh, element):  # basis.py:87-88
+        return mesh["cells", "coordinates"].mT @ element.barycentric_grad
+
+    def interpolate(self, basis, tensor=None):
+        """Evaluate a DoF vector (or a function of the nodes) at this basis's own
+        quadrature points or on the interior edges (basis.py:98-177).  Post-processing,
+        outside the assembly kernel: torch expressions."""
+        from .edges import InteriorEdgesBasis
+
+        if basis is self:
+            dof_ids = self._global_dofs4elements.unsqueeze(-2)
+            v, v_grad = self.v, self.v_grad
+        elif basis.__class__ == InteriorEdgesBasis:
+            edge_mesh = basis.mesh
+            cell_pairs = edge_mesh["interior_edges", "cells"]
+            gather = edge_mesh.compute_coordinates_4_cells
+            dof_ids = gather(edge_mesh["cells", "vertices"], cell_pairs).unsqueeze(-2)
+            origin = gather(self.mesh["cells", "coordinates"][..., [0], :], cell_pairs).unsqueeze(-3)
+            inv_jac = gather(self._inv_map_jacobian, cell_pairs)
+            edge_points = basis.integration_points.unsqueeze(-3)
+            local_points = self._element.compute_inverse_map(origin, edge_points, inv_jac)
+            bar = self._element.compute_barycentric_coordinates(local_points.squeeze(-3))
+            v, v_grad = self._element.compute_shape_functions(bar, inv_jac)
+        else:
+            raise NotImplementedError("Interpolation for this basis not implemented")
+
+        if tensor is not None:
+            nodal = tensor[dof_ids]
+            return (nodal * v).sum(-2, keepdim=True), (nodal * v_grad).sum(-2, keepdim=True)
+
+        nodes = self._coords4global_dofs
+
+        def interpolator(function):
+            return (function(nodes)[dof_ids] * v).sum(-2, keepdim=True)
+
+        def interpolator_grad(function):
+            return (function(nodes)[dof_ids] * v_grad).sum(-2, keepdim=True)
+
+        return interpolator, interpolator_grad

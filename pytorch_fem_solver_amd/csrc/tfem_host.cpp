@@ -1,0 +1,288 @@
+// Host side of libtfem_hip: status/error plumbing, reference-element tables and the
+// symbolic (CSR pattern + slot map) phase.  No device code in this file.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "tfem_common.hpp"
+
+namespace tfem {
+
+static thread_local char g_last_error[512] = "";
+
+int fail(int status, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+// Literals of the reference, element_tri.py:77-130 (15-digit truncations included).
+bool triangle_rule(int quad_order, int *nq, double nodes[kMaxQuad][2], double weights[kMaxQuad]) {
+  switch (quad_order) {
+    case 1:
+      *nq = 1;
+      nodes[0][0] = 1.0 / 3;
+      nodes[0][1] = 1.0 / 3;
+      weights[0] = 1.0;
+      return true;
+    case 2: {
+      *nq = 3;
+      const double n[3][2] = {{1.0 / 6, 1.0 / 6}, {2.0 / 3, 1.0 / 6}, {1.0 / 6, 2.0 / 3}};
+      for (int q = 0; q < 3; ++q) {
+        nodes[q][0] = n[q][0];
+        nodes[q][1] = n[q][1];
+        weights[q] = 1.0 / 3;
+      }
+      return true;
+    }
+    case 3: {
+      *nq = 4;
+      const double n[4][2] = {{1.0 / 3, 1.0 / 3}, {0.6, 0.2}, {0.2, 0.6}, {0.2, 0.2}};
+      const double w[4] = {-9.0 / 16, 25.0 / 48, 25.0 / 48, 25.0 / 48};
+      for (int q = 0; q < 4; ++q) {
+        nodes[q][0] = n[q][0];
+        nodes[q][1] = n[q][1];
+        weights[q] = w[q];
+      }
+      return true;
+    }
+    case 4: {
+      *nq = 6;
+      const double n[6][2] = {{0.816847572980459, 0.091576213509771},
+                              {0.091576213509771, 0.816847572980459},
+                              {0.091576213509771, 0.091576213509771},
+                              {0.108103018168070, 0.445948490915965},
+                              {0.445948490915965, 0.108103018168070},
+                              {0.445948490915965, 0.445948490915965}};
+      for (int q = 0; q < 6; ++q) {
+        nodes[q][0] = n[q][0];
+        nodes[q][1] = n[q][1];
+        weights[q] = q < 3 ? 0.109951743655322 : 0.223381589678011;
+      }
+      return true;
+    }
+    default:
+      return false;
+  }
+}
+
+template <typename T>
+static void fill_tables(int nq, const double nodes[kMaxQuad][2], const double weights[kMaxQuad],
+                        TriTables *t) {
+  // barycentric_grad, element_tri.py:10-12
+  const T g[3][2] = {{T(-1), T(-1)}, {T(1), T(0)}, {T(0), T(1)}};
+  t->nq = nq;
+  for (int q = 0; q < nq; ++q) {
+    const T xi = T(nodes[q][0]), eta = T(nodes[q][1]);
+    const T w = T(weights[q]);
+    t->hw[q] = double(T(0.5) * w);  // reference_element_area * gaussian_weights
+    // element_tri.py:23-26
+    const T l[3] = {T(T(1.0) - xi) - eta, xi, eta};
+    for (int i = 0; i < 3; ++i) t->lam[q][i] = double(l[i]);
+    // element_tri.py:45-55
+    t->phi2[q][0] = double(l[0] * (T(2) * l[0] - T(1)));
+    t->phi2[q][1] = double(l[1] * (T(2) * l[1] - T(1)));
+    t->phi2[q][2] = double(l[2] * (T(2) * l[2] - T(1)));
+    t->phi2[q][3] = double(T(4) * l[0] * l[1]);
+    t->phi2[q][4] = double(T(4) * l[1] * l[2]);
+    t->phi2[q][5] = double(T(4) * l[2] * l[0]);
+    // element_tri.py:57-68
+    for (int c = 0; c < 2; ++c) {
+      t->rgrad2[q][0][c] = double((T(4) * l[0] - T(1)) * g[0][c]);
+      t->rgrad2[q][1][c] = double((T(4) * l[1] - T(1)) * g[1][c]);
+      t->rgrad2[q][2][c] = double((T(4) * l[2] - T(1)) * g[2][c]);
+      t->rgrad2[q][3][c] = double(T(4) * (l[1] * g[0][c] + l[0] * g[1][c]));
+      t->rgrad2[q][4][c] = double(T(4) * (l[2] * g[1][c] + l[1] * g[2][c]));
+      t->rgrad2[q][5][c] = double(T(4) * (l[0] * g[2][c] + l[2] * g[0][c]));
+    }
+  }
+}
+
+bool build_tri_tables(int quad_order, int real_bytes, TriTables *out) {
+  int nq = 0;
+  double nodes[kMaxQuad][2], weights[kMaxQuad];
+  if (!triangle_rule(quad_order, &nq, nodes, weights)) return false;
+  std::memset(out, 0, sizeof(*out));
+  if (real_bytes == 4)
+    fill_tables<float>(nq, nodes, weights, out);
+  else
+    fill_tables<double>(nq, nodes, weights, out);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------
+// symbolic phase
+// ---------------------------------------------------------------------------------
+namespace {
+
+template <typename I>
+int check_conn(const I *conn, int64_t count, int64_t n_dofs) {
+  for (int64_t k = 0; k < count; ++k) {
+    if (conn[k] < 0 || int64_t(conn[k]) >= n_dofs)
+      return fail(TFEM_ERR_INDEX_RANGE, "connectivity entry %lld = %lld outside [0, %lld)",
+                  (long long)k, (long long)conn[k], (long long)n_dofs);
+  }
+  return TFEM_OK;
+}
+
+// Per-row sorted unique column lists.  Row r receives, from every element that contains
+// DoF r, all n DoFs of that element (the pattern is symmetric, so the transposed scatter
+// convention does not change it).  bucket_ptr/bucket hold the duplicated lists.
+template <typename I>
+void build_rows(const I *conn, int64_t n_elems, int n, int64_t n_dofs,
+                std::vector<int64_t> &row_start, std::vector<int32_t> &cols,
+                std::vector<int32_t> &row_len) {
+  std::vector<int64_t> count(n_dofs + 1, 0);
+  for (int64_t k = 0; k < n_elems * n; ++k) count[int64_t(conn[k]) + 1] += n;
+  row_start.assign(n_dofs + 1, 0);
+  std::partial_sum(count.begin(), count.end(), row_start.begin());
+  cols.resize(size_t(row_start[n_dofs]));
+  std::vector<int64_t> cursor(row_start.begin(), row_start.end() - 1);
+  for (int64_t e = 0; e < n_elems; ++e) {
+    const I *c = conn + e * n;
+    for (int a = 0; a < n; ++a) {
+      int64_t &pos = cursor[int64_t(c[a])];
+      for (int b = 0; b < n; ++b) cols[size_t(pos++)] = int32_t(c[b]);
+    }
+  }
+  row_len.resize(size_t(n_dofs));
+  for (int64_t r = 0; r < n_dofs; ++r) {
+    int32_t *first = cols.data() + row_start[r];
+    int32_t *last = cols.data() + row_start[r + 1];
+    std::sort(first, last);
+    row_len[size_t(r)] = int32_t(std::unique(first, last) - first);
+  }
+}
+
+template <typename I>
+int symbolic_count(const I *conn, int64_t n_elems, int n, int64_t n_dofs, int64_t *rowptr,
+                   int64_t *nnz) {
+  if (int st = check_conn(conn, n_elems * n, n_dofs)) return st;
+  std::vector<int64_t> row_start;
+  std::vector<int32_t> cols, row_len;
+  build_rows(conn, n_elems, n, n_dofs, row_start, cols, row_len);
+  rowptr[0] = 0;
+  for (int64_t r = 0; r < n_dofs; ++r) rowptr[r + 1] = rowptr[r] + row_len[size_t(r)];
+  *nnz = rowptr[n_dofs];
+  if (*nnz >= (int64_t(1) << 31))
+    return fail(TFEM_ERR_INDEX_RANGE, "nnz = %lld does not fit the int32 slot map",
+                (long long)*nnz);
+  return TFEM_OK;
+}
+
+template <typename I>
+int symbolic_fill(const I *conn, int64_t n_elems, int n, int64_t n_dofs, const int64_t *rowptr,
+                  int32_t *colind, int32_t *slots) {
+  if (int st = check_conn(conn, n_elems * n, n_dofs)) return st;
+  std::vector<int64_t> row_start;
+  std::vector<int32_t> cols, row_len;
+  build_rows(conn, n_elems, n, n_dofs, row_start, cols, row_len);
+  for (int64_t r = 0; r < n_dofs; ++r) {
+    if (rowptr[r + 1] - rowptr[r] != row_len[size_t(r)])
+      return fail(TFEM_ERR_INVALID_ARGUMENT, "rowptr does not belong to this connectivity");
+    std::copy_n(cols.data() + row_start[r], row_len[size_t(r)], colind + rowptr[r]);
+  }
+  // slots[e][i][j] -> position of (row conn[j], col conn[i]): basis.py:73-76 builds
+  // rows_idx by tiling conn and cols_idx by repeating it, the value is local.reshape(-1).
+  for (int64_t e = 0; e < n_elems; ++e) {
+    const I *c = conn + e * n;
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) {
+        const int64_t row = int64_t(c[j]);
+        const int32_t col = int32_t(c[i]);
+        const int32_t *first = colind + rowptr[row];
+        const int32_t *last = colind + rowptr[row + 1];
+        const int32_t *hit = std::lower_bound(first, last, col);
+        slots[(e * n + i) * n + j] = int32_t(hit - colind);
+      }
+    }
+  }
+  return TFEM_OK;
+}
+
+int check_symbolic_args(const void *conn, int idx_bytes, int64_t n_elems, int n_local,
+                        int64_t n_dofs) {
+  if (!conn && n_elems > 0) return fail(TFEM_ERR_INVALID_ARGUMENT, "conn is NULL");
+  if (idx_bytes != 4 && idx_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "idx_bytes must be 4 or 8, got %d", idx_bytes);
+  if (n_elems < 0 || n_dofs < 0 || n_local < 1 || n_local > 16)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad sizes n_elems=%lld n_local=%d n_dofs=%lld",
+                (long long)n_elems, n_local, (long long)n_dofs);
+  if (n_dofs >= (int64_t(1) << 31))
+    return fail(TFEM_ERR_INDEX_RANGE, "n_dofs = %lld does not fit int32 column indices",
+                (long long)n_dofs);
+  return TFEM_OK;
+}
+
+}  // namespace
+}  // namespace tfem
+
+extern "C" {
+
+int tfem_abi_version(void) { return TFEM_ABI_VERSION; }
+
+const char *tfem_status_string(int status) {
+  switch (status) {
+    case TFEM_OK: return "ok";
+    case TFEM_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case TFEM_ERR_UNSUPPORTED: return "not implemented";
+    case TFEM_ERR_HIP: return "HIP runtime error";
+    case TFEM_ERR_INDEX_RANGE: return "index out of range";
+    case TFEM_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+const char *tfem_last_error(void) { return tfem::g_last_error; }
+
+int tfem_quadrature_size(int quad_order) {
+  int nq = 0;
+  double nodes[tfem::kMaxQuad][2], weights[tfem::kMaxQuad];
+  return tfem::triangle_rule(quad_order, &nq, nodes, weights) ? nq : 0;
+}
+
+int tfem_quadrature_rule(int quad_order, double *nodes_host, double *weights_host) {
+  int nq = 0;
+  double nodes[tfem::kMaxQuad][2], weights[tfem::kMaxQuad];
+  if (!tfem::triangle_rule(quad_order, &nq, nodes, weights))
+    return tfem::fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
+  if (!nodes_host || !weights_host)
+    return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL output");
+  for (int q = 0; q < nq; ++q) {
+    nodes_host[2 * q] = nodes[q][0];
+    nodes_host[2 * q + 1] = nodes[q][1];
+    weights_host[q] = weights[q];
+  }
+  return TFEM_OK;
+}
+
+int tfem_csr_symbolic_count(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                            int64_t n_dofs, int64_t *rowptr_host, int64_t *nnz_host) {
+  if (int st = tfem::check_symbolic_args(conn_host, idx_bytes, n_elems, n_local, n_dofs))
+    return st;
+  if (!rowptr_host || !nnz_host) return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL output");
+  if (idx_bytes == 4)
+    return tfem::symbolic_count(static_cast<const int32_t *>(conn_host), n_elems, n_local,
+                                n_dofs, rowptr_host, nnz_host);
+  return tfem::symbolic_count(static_cast<const int64_t *>(conn_host), n_elems, n_local, n_dofs,
+                              rowptr_host, nnz_host);
+}
+
+int tfem_csr_symbolic_fill(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                           int64_t n_dofs, const int64_t *rowptr_host, int32_t *colind_host,
+                           int32_t *slots_host) {
+  if (int st = tfem::check_symbolic_args(conn_host, idx_bytes, n_elems, n_local, n_dofs))
+    return st;
+  if (!rowptr_host || (!colind_host && rowptr_host[n_dofs] > 0) || (!slots_host && n_elems > 0))
+    return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (idx_bytes == 4)
+    return tfem::symbolic_fill(static_cast<const int32_t *>(conn_host), n_elems, n_local, n_dofs,
+                               rowptr_host, colind_host, slots_host);
+  return tfem::symbolic_fill(static_cast<const int64_t *>(conn_host), n_elems, n_local, n_dofs,
+                             rowptr_host, colind_host, slots_host);
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Multi-GPU assembly: shard the mesh by element range, exchange only the shared DoFs.
+
+The reference is single-process.  Here every rank (one process
+per GPU, ``torch.distributed`` over RCCL/xGMI) assembles its own element range into its
+own local CSR operator / load vector with the same HIP kernels, and the entries that
+receive contributions from more than one rank -- CSR entries (i, j) and vector entries i
+whose DoFs lie on an inter-rank interface -- are summed with ONE all-reduce of a packed
+interface buffer.  The result stays row-distributed: each rank ends up with complete
+values for every row it holds; nothing is replicated beyond the interface.
+
+The exchange is backend-agnostic (``nccl`` = RCCL on GPUs, ``gloo`` in the CPU tests).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .meshgen import morton_order
+
+__all__ = ["partition_elements", "extract_shard", "InterfaceExchange"]
+
+
+def partition_elements(vertices, triangles, world, order="morton"):
+    """Contiguous element ranges after a space-filling-curve sort of the centroids.
+
+    Returns ``element_order`` (permutation of element ids) and ``bounds`` (world+1):
+    rank r owns ``element_order[bounds[r]:bounds[r+1]]``.
+    """
+    tri = np.asarray(triangles, dtype=np.int64)
+    if order == "morton":
+        centroids = np.asarray(vertices)[tri].mean(axis=1)
+        element_order = morton_order(centroids)
+    elif order == "native":
+        element_order = np.arange(tri.shape[0])
+    else:
+        raise ValueError(order)
+    bounds = np.linspace(0, tri.shape[0], world + 1).astype(np.int64)
+    return element_order, bounds
+
+
+def extract_shard(mesh, element_ids):
+    """Local mesh of one rank: its elements with vertices renumbered 0..n_local-1 in
+    ascending global id.  Returns (local mesh dict, local_to_global vertex ids)."""
+    tri = np.asarray(mesh["triangles"], dtype=np.int64)[element_ids]
+    local_to_global = np.unique(tri)
+    local_tri = np.searchsorted(local_to_global, tri).astype(np.int32)
+    local = {
+        "vertices": np.ascontiguousarray(np.asarray(mesh["vertices"])[local_to_global]),
+        "vertex_markers": np.ascontiguousarray(np.asarray(mesh["vertex_markers"])[local_to_global]),
+        "triangles": np.ascontiguousarray(local_tri),
+    }
+    return local, local_to_global
+
+
+def _csr_positions(rowptr, colind, rows, cols):
+    """Position of (rows[k], cols[k]) in a CSR pattern with ascending columns per row."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colind = np.asarray(colind, dtype=np.int64)
+    n = rowptr.shape[0] - 1
+    row_of_entry = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    width = int(colind.max()) + 1 if colind.size else 1
+    keys = row_of_entry * width + colind  # ascending by construction
+    want = np.asarray(rows, dtype=np.int64) * width + np.asarray(cols, dtype=np.int64)
+    pos = np.searchsorted(keys, want)
+    if not np.array_equal(keys[np.clip(pos, 0, keys.size - 1)], want):
+        raise ValueError("interface entry missing from the local CSR pattern")
+    return pos
+
+
+class InterfaceExchange:
+    """Packed interface buffer + one all-reduce.
+
+    ``k_idx`` / ``f_idx``: positions in the local CSR values / local vector;
+    ``k_pos`` / ``f_pos``: positions in the global interface buffer (same on every rank
+    that shares the entry).  Buffer layout: [matrix entries | vector entries].
+    """
+
+    def __init__(self, k_idx, k_pos, f_idx, f_pos, n_matrix, n_vector, device, dtype, group=None):
+        as_long = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64), device=device)  # noqa: E731
+        self.k_idx, self.k_pos = as_long(k_idx), as_long(k_pos)
+        self.f_idx, self.f_pos = as_long(f_idx), as_long(f_pos) + int(n_matrix)
+        self.n_matrix, self.n_vector = int(n_matrix), int(n_vector)
+        self.buffer = torch.zeros(self.n_matrix + self.n_vector, dtype=dtype, device=device)
+        self.group = group
+
+    @property
+    def nbytes(self):
+        return self.buffer.numel() * self.buffer.element_size()
+
+    def reduce(self, vals=None, f=None):
+        """Sum the shared entries of ``vals`` (local CSR values) and ``f`` (local vector,
+        any shape with N_local entries) across ranks, in place."""
+        import torch.distributed as dist
+
+        buf = self.buffer
+        buf.zero_()
+        if vals is not None:
+            buf[self.k_pos] = vals[self.k_idx]
+        if f is not None:
+            flat_f = f.view(-1)
+            buf[self.f_pos] = flat_f[self.f_idx]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if vals is not None:
+            vals[self.k_idx] = buf[self.k_pos]
+        if f is not None:
+            flat_f[self.f_idx] = buf[self.f_pos]
+        return vals, f
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_partition(cls, mesh, element_order, bounds, rank, rowptr, colind, local_to_global,
+                       device, dtype, group=None):
+        """General element-range partition of ONE global mesh (BASELINE config 4).
+
+        Every rank derives the same global interface numbering from the global
+        connectivity, so no communication is needed to set up the exchange.
+        """
+        tri = np.asarray(mesh["triangles"], dtype=np.int64)
+        n_global = int(np.asarray(mesh["vertices"]).shape[0])
+        world = len(bounds) - 1
+        touches = np.zeros(n_global, dtype=np.int32)
+        for r in range(world):
+            ids = element_order[bounds[r]:bounds[r + 1]]
+            touches[np.unique(tri[ids])] += 1
+        shared_vertex = touches > 1
+        shared_ids = np.nonzero(shared_vertex)[0]
+        # interface matrix entries: ordered pairs of shared vertices inside one element
+        in_elem = shared_vertex[tri]
+        cand = tri[in_elem.sum(axis=1) >= 1]
+        pairs = np.stack(
+            [np.repeat(cand, 3, axis=1).reshape(-1), np.tile(cand, (1, 3)).reshape(-1)], axis=1
+        )
+        pairs = pairs[shared_vertex[pairs[:, 0]] & shared_vertex[pairs[:, 1]]]
+        global_keys = np.unique(pairs[:, 0] * n_global + pairs[:, 1])
+        # what this rank holds of it
+        l2g = np.asarray(local_to_global, dtype=np.int64)
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        row_of_entry = np.repeat(np.arange(rowptr.shape[0] - 1, dtype=np.int64), np.diff(rowptr))
+        gi, gj = l2g[row_of_entry], l2g[np.asarray(colind, dtype=np.int64)]
+        mine = np.nonzero(shared_vertex[gi] & shared_vertex[gj])[0]
+        k_pos = np.searchsorted(global_keys, gi[mine] * n_global + gj[mine])
+        f_idx = np.nonzero(shared_vertex[l2g])[0]
+        f_pos = np.searchsorted(shared_ids, l2g[f_idx])
+        return cls(mine, k_pos, f_idx, f_pos, global_keys.size, shared_ids.size, device, dtype, group)
+
+    @classmethod
+    def for_strips(cls, mesh, rank, world, engine, group=None):
+        """Weak-scaling layout of bench.py: rank r holds the structured strip
+        [r, r+1] x [0, 1] (n x n cells, vertex id iy*(n+1)+ix); its right column is the
+        left column of rank r+1.  Interface k (between ranks k and k+1) carries, for the
+        n+1 column vertices, the diagonal entries, the 2n entries of the vertical edges
+        and the n+1 vector entries."""
+        n = int(round(np.sqrt(mesh["triangles"].shape[0] // 2)))
+        nvx = n + 1
+        rowptr, colind, _ = engine.csr_structure()
+        rowptr, colind = rowptr.cpu().numpy(), colind.cpu().numpy()
+        iy = np.arange(nvx, dtype=np.int64)
+        per_k = nvx + 2 * n
+        k_idx, k_pos, f_idx, f_pos = [], [], [], []
+        for interface, ix in ((rank - 1, 0), (rank, n)):
+            if interface < 0 or interface >= world - 1:
+                continue
+            col = iy * nvx + ix
+            rows = np.concatenate([col, col[:-1], col[1:]])
+            cols = np.concatenate([col, col[1:], col[:-1]])
+            k_idx.append(_csr_positions(rowptr, colind, rows, cols))
+            k_pos.append(interface * per_k + np.arange(per_k))
+            f_idx.append(col)
+            f_pos.append(interface * nvx + iy)
+        cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)  # noqa: E731
+        return cls(cat(k_idx), cat(k_pos), cat(f_idx), cat(f_pos), max(world - 1, 0) * per_k,
+                   max(world - 1, 0) * nvx, engine.device, engine.dtype, group)

@@ -1,0 +1,355 @@
+"""Parity of the HIP assembly path (through the C ABI) with the CPU oracle and with the
+reference-generated golden fixtures.  Runs on a real MI355X only (-m gpu).
+
+Tolerance: fp64, scaled max-abs and relative-Frobenius error <= 1e-12 (BASELINE.json
+north_star); float32 <= 2e-6.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, mesh_from_golden, scaled_error
+from oracle import assembly_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(autouse=True)
+def _gpu_defaults():
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    torch.set_default_device("cuda")
+    yield
+    torch.set_default_device("cpu")
+    torch.set_default_dtype(torch.float32)
+
+
+def tf():
+    import pytorch_fem_solver_amd
+
+    return pytorch_fem_solver_amd
+
+
+def stiffness(basis):
+    return basis.v_grad @ basis.v_grad.mT
+
+
+def stiffness_mass(basis):
+    return basis.v_grad @ basis.v_grad.mT + basis.v @ basis.v.mT
+
+
+def mass(basis):
+    return basis.v @ basis.v.mT
+
+
+def convection_x(basis):
+    return basis.v @ basis.v_grad[..., [0]].mT
+
+
+def rhs(x, y):
+    return 2.0 * math.pi**2 * torch.sin(math.pi * x) * torch.sin(math.pi * y)
+
+
+def load(basis):
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    return rhs(x, y) * basis.v
+
+
+def rhs_squared(basis):
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    return rhs(x, y) ** 2
+
+
+def grad_field(points):
+    x, y = torch.split(points, 1, dim=-1)
+    return torch.cat([torch.cos(3.0 * x) * y, x * x - torch.sin(2.0 * y)], dim=-1)
+
+
+def weak_residual(basis, field):
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    return rhs(x, y) * basis.v - (basis.v_grad @ field(basis.integration_points).mT)
+
+
+def test_native_library_is_the_one_loaded():
+    from pytorch_fem_solver_amd import _native
+
+    lib = _native.load()
+    assert lib.tfem_device_count() >= 1
+    with open("/proc/self/maps") as maps:
+        assert "libtfem_hip.so" in maps.read()
+
+
+@pytest.mark.parametrize(
+    "fixture,orders",
+    [
+        ("p1_square_n8.npz", (1, 2, 3, 4)),
+        ("p1_square_n5_clockwise.npz", (3,)),
+        ("p1_delaunay_170.npz", (3,)),
+    ],
+)
+def test_p1_against_golden(fixture, orders):
+    d = load_golden(fixture)
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    for order in orders:
+        basis = tf().Basis(mesh, tf().ElementTri(polynomial_order=1, integration_order=order))
+        tag = f"out_q{order}_"
+        # geometry cache in the reference's shapes
+        assert scaled_error(basis.v.cpu(), d[tag + "v"]) <= TOL
+        assert scaled_error(basis.v_grad.cpu(), d[tag + "v_grad"]) <= TOL
+        assert scaled_error(basis.integration_points.cpu(), d[tag + "integration_points"]) <= TOL
+        assert scaled_error(basis._dx.cpu(), d[tag + "dx"]) <= TOL
+        assert scaled_error(basis._inv_map_jacobian.cpu(), d[tag + "inv_map_jacobian"]) <= TOL
+        # fused forms
+        for name, form in (
+            ("K_stiffness", stiffness),
+            ("K_stiffness_mass", stiffness_mass),
+            ("K_mass", mass),
+            ("K_convection_x", convection_x),  # generic reduce+scatter, non-symmetric
+        ):
+            dense = basis.integrate_bilinear_form(form)
+            assert dense.is_cuda and dense.shape == d[tag + name].shape
+            assert scaled_error(dense.cpu(), d[tag + name]) <= TOL, (name, order)
+            csr = basis.integrate_bilinear_form(form, layout="csr")
+            assert scaled_error(csr.to_dense().cpu(), d[tag + name]) <= TOL
+        f = basis.integrate_linear_form(load)
+        assert f.shape == d[tag + "f_load"].shape
+        assert scaled_error(f.cpu(), d[tag + "f_load"]) <= TOL
+        fw = basis.integrate_linear_form(weak_residual, grad_field)  # generic linear path
+        assert scaled_error(fw.cpu(), d[tag + "f_weak_residual"]) <= TOL
+        fun = basis.integrate_functional(rhs_squared)
+        assert fun.shape == d[tag + "functional_rhs2"].shape
+        assert scaled_error(fun.cpu(), d[tag + "functional_rhs2"]) <= TOL
+        # downstream: solve + interpolate (torch host code fed by the assembled operator)
+        A = basis.integrate_bilinear_form(stiffness)
+        u = basis.solve(A, basis.solution_tensor(), f)
+        assert scaled_error(u.cpu(), d[tag + "u_h"]) <= 1e-10
+        val, grad = basis.interpolate(basis, u)
+        assert scaled_error(val.cpu(), d[tag + "interp_self_val"]) <= 1e-10
+        assert scaled_error(grad.cpu(), d[tag + "interp_self_grad"]) <= 1e-10
+
+
+def test_generic_path_equals_fused_path():
+    d = load_golden("p1_square_n8.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+
+    def opaque(b):  # same form, written so the tracer cannot recognise it
+        g = b.v_grad
+        return torch.matmul(g, g.transpose(-1, -2)) + b.v @ b.v.mT
+
+    fused = basis.integrate_bilinear_form(stiffness_mass)
+    generic = basis.integrate_bilinear_form(opaque)
+    assert scaled_error(generic.cpu(), fused.cpu()) <= 1e-14
+
+
+def test_cpu_resident_mesh_is_staged_through_the_gpu():
+    """tests/test_assembly.py of the reference runs with CPU default tensors."""
+    torch.set_default_device("cpu")
+    d = load_golden("p1_delaunay_170.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+    K = basis.integrate_bilinear_form(stiffness_mass)
+    f = basis.integrate_linear_form(load)
+    fun = basis.integrate_functional(rhs_squared)
+    assert not K.is_cuda and not f.is_cuda and not fun.is_cuda
+    assert scaled_error(K, d["out_q3_K_stiffness_mass"]) <= TOL
+    assert scaled_error(f, d["out_q3_f_load"]) <= TOL
+    assert scaled_error(fun, d["out_q3_functional_rhs2"]) <= TOL
+
+
+def test_float32():
+    torch.set_default_dtype(torch.float32)
+    d = load_golden("p1_square_n6_float32.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 4))
+    assert basis.v_grad.dtype == torch.float32
+    assert scaled_error(basis.v_grad.cpu(), d["out_q4_v_grad"]) <= 2e-6
+    K = basis.integrate_bilinear_form(stiffness)
+    assert K.dtype == torch.float32
+    assert scaled_error(K.cpu(), d["out_q4_K_stiffness"]) <= 2e-6
+    f = basis.integrate_linear_form(load)
+    assert scaled_error(f.cpu(), d["out_q4_f_load"]) <= 2e-6
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_p2_global_against_golden(order):
+    d = load_golden("p2_global_n4.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(polynomial_order=2, integration_order=order))
+    assert np.array_equal(basis._global_dofs4elements.cpu().numpy(), d["in_p2_connectivity"])
+    tag = f"out_q{order}_"
+    K = basis.integrate_bilinear_form(stiffness)
+    assert scaled_error(K.cpu(), d[tag + "K_stiffness"]) <= TOL
+    KM = basis.integrate_bilinear_form(stiffness_mass)
+    assert scaled_error(KM.cpu(), d[tag + "K_stiffness_mass"]) <= TOL
+    f = basis.integrate_linear_form(load)
+    assert scaled_error(f.cpu(), d[tag + "f_load"]) <= TOL
+
+
+@pytest.mark.parametrize("order", [2, 3, 4])
+def test_p2_element_level_geometry(order):
+    """P2 v_grad (N_T, Q, 6, 2) from the geometry kernel vs the reference element code."""
+    d = load_golden("p2_element.npz")
+    cells = d["in_cell_coordinates"]
+    n = cells.shape[0]
+    mesh_np = {
+        "vertices": cells.reshape(-1, 2),
+        "vertex_markers": np.zeros((3 * n, 1), dtype=np.int32),
+        "triangles": np.arange(3 * n, dtype=np.int32).reshape(n, 3),
+    }
+    mesh = tf().MeshTri(triangulation=mesh_np)
+    basis = tf().Basis(mesh, tf().ElementTri(polynomial_order=2, integration_order=order))
+    tag = f"out_q{order}_"
+    assert scaled_error(basis.v.cpu(), d[tag + "v"]) <= TOL
+    assert scaled_error(basis.v_grad.cpu(), d[tag + "v_grad"]) <= TOL
+    assert scaled_error(basis._dx.cpu(), d[tag + "dx"]) <= TOL
+
+
+@pytest.mark.parametrize("fixture", ["fracture_L4.npz", "fracture_L3_jitter.npz"])
+def test_fracture_example_pipeline(fixture):
+    """Config 5: examples/example_fractures_fem.py:58-64,235-297 on the committed mesh."""
+    d = load_golden(fixture)
+    tri = mesh_from_golden(d)
+    mesh = tf().FracturesTri(
+        triangulations=[tri, tri], fractures_3d_data=torch.tensor(d["in_fractures_3d"])
+    )
+    V = tf().FractureBasis(mesh, tf().ElementTri(polynomial_order=1, integration_order=4))
+    assert scaled_error(V.v_grad.cpu(), d["out_frac_v_grad"]) <= TOL
+    assert scaled_error(V._dx.cpu(), d["out_frac_dx"]) <= TOL
+    assert scaled_error(V.integration_points.cpu(), d["out_frac_integration_points"]) <= TOL
+    assert scaled_error(V._inv_map_jacobian.cpu(), d["out_frac_inv_map_jacobian"]) <= TOL
+
+    def frac_rhs(c):
+        x, y, z = torch.split(c, 1, dim=-1)
+        x1, _ = torch.split(x, 1, dim=0)
+        y1, y2 = torch.split(y, 1, dim=0)
+        _, z2 = torch.split(z, 1, dim=0)
+        r1 = 6.0 * (y1 - y1**2) * torch.abs(x1) - 2.0 * (torch.abs(x1) ** 3 - torch.abs(x1))
+        r2 = -6.0 * (y2 - y2**2) * torch.abs(z2) + 2.0 * (torch.abs(z2) ** 3 - torch.abs(z2))
+        return torch.cat([r1, r2], dim=0)
+
+    def exact(c):
+        x, y, z = torch.split(c, 1, dim=-1)
+        x1, _ = torch.split(x, 1, dim=0)
+        y1, y2 = torch.split(y, 1, dim=0)
+        _, z2 = torch.split(z, 1, dim=0)
+        e1 = -y1 * (1 - y1) * torch.abs(x1) * (x1**2 - 1)
+        e2 = y2 * (1 - y2) * torch.abs(z2) * (z2**2 - 1)
+        return torch.cat([e1, e2], dim=0)
+
+    A = V.integrate_bilinear_form(stiffness)
+    b = V.integrate_linear_form(lambda basis: frac_rhs(basis.integration_points) * basis.v)
+    fun = V.integrate_functional(lambda basis: exact(basis.integration_points) ** 2)
+    assert scaled_error(A.cpu(), d["out_A"]) <= TOL
+    assert scaled_error(b.cpu(), d["out_b"]) <= TOL
+    assert scaled_error(fun.cpu(), d["out_functional_exact_sq"]) <= TOL
+    u_h = V.solve(A, V.solution_tensor(), b)
+    assert scaled_error(u_h.cpu(), d["out_u_h"]) <= 1e-10
+    val, grad = V.interpolate(V, u_h)
+    assert scaled_error(val.cpu(), d["out_interp_self_val"]) <= 1e-10
+    assert scaled_error(grad.cpu(), d["out_interp_self_grad"]) <= 1e-10
+    VE = tf().InteriorEdgesFractureBasis(mesh, tf().ElementLine(polynomial_order=1, integration_order=2))
+    assert scaled_error(VE.integration_points.cpu(), d["out_edge_integration_points"]) <= TOL
+    assert scaled_error(VE._dx.cpu(), d["out_edge_dx"]) <= TOL
+    _, eg = V.interpolate(VE, u_h)
+    n_E = mesh["interior_edges", "normals_3d"].unsqueeze(-2)
+    plus, minus = torch.unbind(eg, dim=-4)
+    jump = (plus * n_E).sum(-1) + (minus * -n_E).sum(-1)
+    assert scaled_error(jump.cpu(), d["out_jump"]) <= 1e-9
+
+
+def test_interior_edges_basis_and_interpolation():
+    d = load_golden("mesh_topology_n4.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+    edge_basis = tf().InteriorEdgesBasis(mesh, tf().ElementLine(1, 2))
+    assert scaled_error(edge_basis.integration_points.cpu(), d["out_edge_integration_points"]) <= TOL
+    assert scaled_error(edge_basis._dx.cpu(), d["out_edge_dx"]) <= TOL
+    u = torch.tensor(d["in_vertex_field"])
+    val, grad = basis.interpolate(edge_basis, u)
+    assert scaled_error(val.cpu(), d["out_interp_edges_val"]) <= 1e-11
+    assert scaled_error(grad.cpu(), d["out_interp_edges_grad"]) <= 1e-11
+
+
+# ---------------------------------------------------------------------------------------
+# oracle comparisons on seeded meshes + size-independent properties at full size
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,order", [(71, 3), (200, 4)])
+def test_p1_csr_against_oracle(n, order):
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(n, 0.25, 0)
+    mesh = tf().MeshTri(triangulation=mesh_np)
+    basis = tf().Basis(mesh, tf().ElementTri(1, order))
+    K = basis.integrate_bilinear_form(stiffness_mass, layout="csr")
+    nv = mesh_np["vertices"].shape[0]
+    local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "stiffness_mass")
+    rowptr, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    assert np.array_equal(K.crow_indices.cpu().numpy(), rowptr)
+    assert np.array_equal(K.col_indices.cpu().numpy(), colind)
+    assert scaled_error(K.values.cpu(), want) <= TOL
+    f = basis.integrate_linear_form(load)
+    fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "load")
+    assert scaled_error(f.cpu(), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
+
+
+def test_edge_cases_empty_and_single_element():
+    mesh_np = {
+        "vertices": np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 1.0]]),
+        "vertex_markers": np.ones((3, 1), dtype=np.int32),
+        "triangles": np.array([[0, 1, 2]], dtype=np.int32),
+        "edges": np.array([[0, 1], [1, 2], [0, 2]], dtype=np.int32),
+        "edge_markers": np.ones((3, 1), dtype=np.int32),
+    }
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 2))
+    K = basis.integrate_bilinear_form(stiffness)
+    want = orc.p1_stiffness_closed_form(mesh_np["vertices"], mesh_np["triangles"])[0]
+    # local[i, j] -> A[conn[j], conn[i]]; symmetric here
+    assert scaled_error(K.cpu(), want) <= TOL
+
+
+def test_unsupported_orders_raise_like_the_reference():
+    with pytest.raises(NotImplementedError):
+        tf().ElementTri(1, 5)
+    d = load_golden("p1_square_n8.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    with pytest.raises(NotImplementedError):
+        tf().Basis(mesh, tf().ElementTri(3, 2))
+
+
+def test_full_size_properties_1e6():
+    """C2 (999,698 elements): properties that need no oracle -- row sums of the stiffness
+    operator vanish, sum(M) = |Omega| = 1, sum(f) = quadrature of the source, symmetry of
+    the CSR values, run-to-run agreement."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(707, 0.25, 0)
+    mesh = tf().MeshTri(triangulation=mesh_np)
+    basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+    K = basis.integrate_bilinear_form(stiffness, layout="csr")
+    assert K.nnz == 3503186
+    ones = torch.ones(K.shape[0], 1)
+    scale = K.values.abs().max().item()
+    assert (K.matvec(ones).abs().max().item()) <= 1e-12 * scale * 8
+    M = basis.integrate_bilinear_form(mass, layout="csr")
+    assert abs(M.values.sum().item() - 1.0) <= 1e-12
+    Kt = K.to_sparse_csr().to_sparse_coo().t().coalesce()
+    Kc = K.to_sparse_csr().to_sparse_coo().coalesce()
+    assert torch.equal(Kt.indices(), Kc.indices())
+    assert (Kt.values() - Kc.values()).abs().max().item() <= 1e-12 * scale
+    f = basis.integrate_linear_form(load)
+    total = basis.integrate_functional(lambda b: rhs(*torch.split(b.integration_points, 1, dim=-1)))
+    assert abs(f.sum().item() - total.sum().item()) <= 1e-11 * abs(total.sum().item())
+    K2 = basis.integrate_bilinear_form(stiffness, layout="csr")
+    assert (K2.values - K.values).abs().max().item() <= 1e-13 * scale
+    # against the oracle on a strided sample of elements (local blocks, closed form)
+    sample = np.arange(0, mesh_np["triangles"].shape[0], 997)
+    local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"][sample], 3, "stiffness")
+    closed = orc.p1_stiffness_closed_form(mesh_np["vertices"], mesh_np["triangles"][sample])
+    assert scaled_error(local, closed) <= 1e-12
