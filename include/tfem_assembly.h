@@ -11,7 +11,8 @@
  * Conventions
  *   - "device" pointers are HIP device pointers valid on the current device;
  *     "host" pointers are ordinary process memory.  The library never
- *     allocates or frees caller-visible memory and keeps no global state.
+ *     allocates or frees caller-visible memory and keeps no global state (the
+ *     only library-owned object is the opaque tile-plan handle, below).
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *     Device entry points only enqueue work; they never synchronise.
  *   - every function returns a tfem_status (0 = success).  tfem_last_error()
@@ -145,6 +146,45 @@ int tfem_reduce_functional(const void *integrand, int real_bytes, int64_t es, in
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
 int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,
                       int real_bytes, int64_t n_dofs, void *dense, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Tile plan (HOST, once per mesh) + tile kernel (DEVICE): the P1 headline path.
+ * The CSR rows (= vertices) are cut into spatially compact tiles along a Z-order
+ * curve; a tile owns its rows, processes every element incident to them,
+ * accumulates in LDS and writes each CSR value once (no global atomics, no
+ * zero-fill).  Replaces, like tfem_tri_bilinear_csr, abstract_basis.py:74-93
+ * fused with abstract_mesh.py:257-262 and basis.py:64-96; requires P1 with DoFs =
+ * vertices (conn indexes coords) and rows of at most 16 entries.
+ *   create : plan handle from connectivity, coordinates (for the curve) and the CSR
+ *            pattern of tfem_csr_symbolic_*; capacities bound a tile's elements,
+ *            local vertices, accumulator entries and owned rows.
+ *   sizes  : [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows
+ *            [4] n_row_loff [5] max elems/tile [6] max verts/tile [7] max owned/tile
+ *            [8] max accumulator entries/tile [9] max row length
+ *   export : copy the plan into caller-owned host arrays:
+ *            desc int32 (8 per tile), records uint32 (3 per element record),
+ *            vert_gid int32, row_gstart int32, row_loff uint16.
+ * The handle is internal library memory and must be released with _destroy.
+ * ------------------------------------------------------------------------- */
+int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
+                          int64_t n_verts, const double *coords_host,
+                          const int64_t *rowptr_host, const int32_t *colind_host,
+                          int elem_cap, int vert_cap, int acc_cap, int own_cap,
+                          void **plan_out);
+int tfem_tile_plan_sizes(const void *plan, int64_t sizes[10]);
+int tfem_tile_plan_export(const void *plan, int32_t *desc, uint32_t *records,
+                          int32_t *vert_gid, int32_t *row_gstart, uint16_t *row_loff);
+void tfem_tile_plan_destroy(void *plan);
+/* Largest elem_cap the compiled kernel accepts. */
+int tfem_tile_elem_capacity(void);
+/* alpha * stiffness + beta * mass into CSR vals (every entry written once; vals need
+ * not be initialised).  All plan arrays are DEVICE copies of the exported ones. */
+int tfem_p1_bilinear_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
+                           double beta, const int32_t *desc, int64_t n_tiles,
+                           const uint32_t *records, const int32_t *vert_gid,
+                           const int32_t *row_gstart, const uint16_t *row_loff,
+                           int max_n_elem, int max_n_vert, int max_n_own, int max_acc,
+                           void *vals, void *stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ this package: without the library or without a GPU every method raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_void_p
 
 import numpy as np
@@ -61,6 +62,56 @@ def symbolic_host(conn_dof, n_dofs):
     return rowptr, colind[: nnz.value], slots[: e * n * n]
 
 
+#: default tile capacities: 45 KB of LDS per workgroup -> 3 workgroups per CU
+TILE_DEFAULTS = {"own": 512, "acc": 4096, "vert": 704}
+
+
+def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=None,
+                   vert_cap=None, elem_cap=None):
+    """Build the tile plan on the host (tfem_tile_plan_*).  Returns a dict of numpy arrays
+    and the size vector, or raises NotImplementedError when the mesh does not fit the
+    plan's format (rows longer than 16 entries)."""
+    lib = _native.load()
+    env = lambda key, default: int(os.environ.get(key, default))  # noqa: E731
+    own_cap = own_cap or env("TFEM_TILE_OWN", TILE_DEFAULTS["own"])
+    acc_cap = acc_cap or env("TFEM_TILE_ACC", TILE_DEFAULTS["acc"])
+    vert_cap = vert_cap or env("TFEM_TILE_VERT", TILE_DEFAULTS["vert"])
+    elem_cap = elem_cap or lib.tfem_tile_elem_capacity()
+    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32)).reshape(-1, 3)
+    coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
+    rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
+    colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
+    handle = c_void_p()
+    _native.check(
+        lib.tfem_tile_plan_create(
+            c_void_p(conn.ctypes.data), 4, conn.shape[0], int(n_verts),
+            c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
+            c_void_p(colind.ctypes.data), elem_cap, vert_cap, acc_cap, own_cap,
+            ctypes.byref(handle),
+        )
+    )
+    try:
+        sizes = np.zeros(10, dtype=np.int64)
+        _native.check(lib.tfem_tile_plan_sizes(handle, c_void_p(sizes.ctypes.data)))
+        plan = {
+            "desc": np.zeros(max(8 * sizes[0], 1), dtype=np.int32),
+            "records": np.zeros(max(3 * sizes[1], 1), dtype=np.uint32),
+            "vert_gid": np.zeros(max(sizes[2], 1), dtype=np.int32),
+            "row_gstart": np.zeros(max(sizes[3], 1), dtype=np.int32),
+            "row_loff": np.zeros(max(sizes[4], 1), dtype=np.uint16),
+        }
+        _native.check(
+            lib.tfem_tile_plan_export(
+                handle, *[c_void_p(plan[k].ctypes.data)
+                          for k in ("desc", "records", "vert_gid", "row_gstart", "row_loff")]
+            )
+        )
+    finally:
+        lib.tfem_tile_plan_destroy(handle)
+    plan["sizes"] = sizes
+    return plan
+
+
 class AssemblyEngine:
     def __init__(self, coords, conn_geo, conn_dof, n_dofs, poly_order, quad_order, fracture=None):
         """coords (N_v,2) or (F,N_v,2); conn_geo (N_T,3) or (F,N_T,3) vertex ids (per mesh);
@@ -88,6 +139,10 @@ class AssemblyEngine:
         self._host_fracture = fracture
         self._dev = None
         self._csr = None
+        self._csr_host = None
+        self._tiles = None
+        #: "auto" (tile plan when the mesh allows it), "tiles" or "atomic"
+        self.kernel = os.environ.get("TFEM_KERNEL", "auto")
 
     # ------------------------------------------------------------------ device state
     @property
@@ -123,6 +178,7 @@ class AssemblyEngine:
         if self._csr is None:
             conn = self._host_conn_dof.cpu().numpy()
             rowptr, colind, slots = symbolic_host(conn, self.n_dofs)
+            self._csr_host = (rowptr, colind)
             dev = self.device
             self._csr = (
                 torch.from_numpy(rowptr).to(dev),
@@ -131,9 +187,44 @@ class AssemblyEngine:
             )
         return self._csr
 
+    def tile_plan(self):
+        """Device copy of the tile plan, or None when this basis cannot use it (P2,
+        fractures, float coordinates of another layout, rows longer than 16 entries)."""
+        if self._tiles is None:
+            self._tiles = False
+            eligible = (
+                self.kernel != "atomic" and self.poly_order == 1 and self.n_fractures == 0
+                and self._host_conn_geo.dim() == 2
+                and torch.equal(self._host_conn_geo.reshape(-1).cpu().long(),
+                                self._host_conn_dof.reshape(-1).cpu().long())
+            )
+            if eligible:
+                self.csr_structure()
+                rowptr, colind = self._csr_host
+                try:
+                    plan = tile_plan_host(
+                        self._host_conn_dof.cpu().numpy(), self.n_dofs,
+                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                    )
+                except NotImplementedError:
+                    plan = None
+                if plan is not None:
+                    dev = self.device
+                    self._tiles = {
+                        k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else
+                                            (v.view(np.int16) if v.dtype == np.uint16 else v)).to(dev)
+                        for k, v in plan.items() if k != "sizes"
+                    }
+                    self._tiles["sizes"] = [int(x) for x in plan["sizes"]]
+            if self._tiles is False and self.kernel == "tiles":
+                raise NotImplementedError("the tile-plan kernel does not apply to this basis")
+        return self._tiles or None
+
     def kernel_name(self):
         """Name of the dominant numeric kernel as rocprofv3 reports it."""
-        return "k_p1_bilinear_atomic" if self.poly_order == 1 else "k_p2_bilinear_atomic"
+        if self.poly_order != 1:
+            return "k_p2_bilinear_atomic"
+        return "k_p1_bilinear_tiles" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
 
     def wrap_csr(self, vals):
         rowptr, colind, _ = self.csr_structure()
@@ -172,6 +263,22 @@ class AssemblyEngine:
     def bilinear(self, alpha: float, beta: float):
         """CSR values of alpha*stiffness + beta*mass (fused kernel)."""
         d = self._inputs()
+        tiles = self.tile_plan()
+        if tiles is not None:
+            sz = tiles["sizes"]
+            vals = torch.empty(int(self.csr_structure()[1].shape[0]), dtype=self.dtype,
+                               device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(
+                    self.lib.tfem_p1_bilinear_tiles(
+                        _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
+                        float(beta), _native.ptr(tiles["desc"]), sz[0],
+                        _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
+                        _native.ptr(tiles["row_gstart"]), _native.ptr(tiles["row_loff"]),
+                        sz[5], sz[6], sz[7], sz[8], _native.ptr(vals), self._stream(),
+                    )
+                )
+            return vals
         _, colind, slots = self.csr_structure()
         nnz = int(colind.shape[0])
         vals = torch.empty(nnz, dtype=self.dtype, device=self.device)

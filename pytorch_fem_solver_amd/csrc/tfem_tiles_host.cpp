@@ -1,0 +1,270 @@
+// Tile plan for the P1 headline path (host, once per mesh).
+//
+// The CSR rows (= vertices) are cut into spatially compact tiles along a Z-order curve.
+// A tile OWNS its rows: it processes every element incident to an owned vertex (elements
+// on a tile border are processed by up to three tiles), accumulates the owned rows in LDS
+// and writes each CSR value exactly once with plain stores -- no global atomics, no
+// zero-fill of the value array, no second pass.  Everything the kernel needs per element
+// is one 12-byte record: the three tile-local vertex ids and, for each of the three rows,
+// the positions of the three columns inside that row.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "tfem_common.hpp"
+
+namespace tfem {
+
+struct TilePlan {
+  // limits the kernel was compiled for
+  int elem_cap = 0, vert_cap = 0, acc_cap = 0;
+  // per tile: elem_off, n_elem, vert_off, n_vert, n_own, row_off, acc_size, loff_off
+  std::vector<int32_t> desc;
+  std::vector<uint32_t> records;    // 3 words per tile element
+  std::vector<int32_t> vert_gid;    // global vertex id of every tile-local vertex
+  std::vector<int32_t> row_gstart;  // rowptr[g] of every owned row
+  std::vector<uint16_t> row_loff;   // n_own + 1 accumulator offsets per tile
+  int32_t max_n_elem = 0, max_n_vert = 0, max_n_own = 0, max_acc = 0, max_row_len = 0;
+  int64_t n_tiles = 0;
+};
+
+namespace {
+
+inline uint64_t spread_bits(uint64_t x) {
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+template <typename I>
+int build(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
+          const int64_t *rowptr, const int32_t *colind, int elem_cap, int vert_cap, int acc_cap,
+          int own_cap, TilePlan &plan) {
+  plan.elem_cap = elem_cap;
+  plan.vert_cap = vert_cap;
+  plan.acc_cap = acc_cap;
+  // ---- Z-order of the vertices ---------------------------------------------------------
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int64_t v = 0; v < n_verts; ++v)
+    for (int c = 0; c < 2; ++c) {
+      lo[c] = std::min(lo[c], coords[2 * v + c]);
+      hi[c] = std::max(hi[c], coords[2 * v + c]);
+    }
+  const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
+  std::vector<std::pair<uint64_t, int32_t>> order(static_cast<size_t>(n_verts));
+  const double scale = double(1u << 24) / span;
+  for (int64_t v = 0; v < n_verts; ++v) {
+    const uint64_t qx = std::min<uint64_t>(uint64_t((coords[2 * v] - lo[0]) * scale), (1u << 24) - 1);
+    const uint64_t qy = std::min<uint64_t>(uint64_t((coords[2 * v + 1] - lo[1]) * scale), (1u << 24) - 1);
+    order[size_t(v)] = {spread_bits(qx) | (spread_bits(qy) << 1), int32_t(v)};
+  }
+  std::sort(order.begin(), order.end());
+  // ---- vertex -> incident elements ------------------------------------------------------
+  std::vector<int64_t> adj_ptr(size_t(n_verts) + 1, 0);
+  for (int64_t k = 0; k < 3 * n_elems; ++k) adj_ptr[size_t(conn[k]) + 1]++;
+  std::partial_sum(adj_ptr.begin(), adj_ptr.end(), adj_ptr.begin());
+  std::vector<int32_t> adj(size_t(3 * n_elems));
+  {
+    std::vector<int64_t> cur(adj_ptr.begin(), adj_ptr.end() - 1);
+    for (int64_t e = 0; e < n_elems; ++e)
+      for (int a = 0; a < 3; ++a) adj[size_t(cur[size_t(conn[3 * e + a])]++)] = int32_t(e);
+  }
+  // ---- greedy tiling along the curve ------------------------------------------------------
+  std::vector<int32_t> elem_stamp(size_t(n_elems), -1), vert_stamp(size_t(n_verts), -1);
+  std::vector<int32_t> vert_local(size_t(n_verts), 0);
+  std::vector<int32_t> owned, tile_elems, halo, new_elems, new_verts;
+  int64_t cursor = 0;
+  int32_t tile = 0;
+  while (cursor < n_verts) {
+    owned.clear();
+    tile_elems.clear();
+    halo.clear();
+    int acc = 0;
+    int n_local = 0;  // vertices referenced so far (owned or not)
+    // phase A: choose the owned vertices of this tile
+    while (cursor < n_verts) {
+      const int32_t u = order[size_t(cursor)].second;
+      const int len = int(rowptr[u + 1] - rowptr[u]);
+      if (len > plan.max_row_len) plan.max_row_len = len;
+      if (len > 16)
+        return fail(TFEM_ERR_UNSUPPORTED, "row of vertex %d has %d entries (> 16)", u, len);
+      new_elems.clear();
+      new_verts.clear();
+      for (int64_t k = adj_ptr[u]; k < adj_ptr[u + 1]; ++k) {
+        const int32_t e = adj[size_t(k)];
+        if (elem_stamp[size_t(e)] == tile) continue;
+        elem_stamp[size_t(e)] = tile;
+        new_elems.push_back(e);
+        for (int a = 0; a < 3; ++a) {
+          const int32_t w = int32_t(conn[3 * int64_t(e) + a]);
+          if (vert_stamp[size_t(w)] != tile) {
+            vert_stamp[size_t(w)] = tile;
+            new_verts.push_back(w);
+          }
+        }
+      }
+      int extra_local = int(new_verts.size());
+      if (vert_stamp[size_t(u)] != tile) {  // isolated vertex: still owns its (empty) row
+        vert_stamp[size_t(u)] = tile;
+        new_verts.push_back(u);
+        extra_local++;
+      }
+      const bool fits = int(tile_elems.size() + new_elems.size()) <= elem_cap &&
+                        n_local + extra_local <= vert_cap && acc + len <= acc_cap &&
+                        int(owned.size()) + 1 <= own_cap;
+      if (!fits && !owned.empty()) {  // roll back and close the tile
+        for (int32_t e : new_elems) elem_stamp[size_t(e)] = -1;
+        for (int32_t w : new_verts) vert_stamp[size_t(w)] = -1;
+        break;
+      }
+      if (!fits)
+        return fail(TFEM_ERR_UNSUPPORTED, "vertex %d alone exceeds the tile capacity", u);
+      owned.push_back(u);
+      tile_elems.insert(tile_elems.end(), new_elems.begin(), new_elems.end());
+      n_local += extra_local;
+      acc += len;
+      ++cursor;
+    }
+    // phase B: local numbering -- owned rows first, ascending global id (contiguous output runs)
+    std::sort(owned.begin(), owned.end());
+    const int n_own = int(owned.size());
+    for (int l = 0; l < n_own; ++l) {
+      vert_local[size_t(owned[size_t(l)])] = l;
+      vert_stamp[size_t(owned[size_t(l)])] = -2 - tile;  // marks "owned by this tile"
+    }
+    int next_local = n_own;
+    const int32_t vert_off = int32_t(plan.vert_gid.size());
+    plan.vert_gid.insert(plan.vert_gid.end(), owned.begin(), owned.end());
+    std::sort(tile_elems.begin(), tile_elems.end());
+    for (int32_t e : tile_elems)
+      for (int a = 0; a < 3; ++a) {
+        const int32_t w = int32_t(conn[3 * int64_t(e) + a]);
+        if (vert_stamp[size_t(w)] == tile) {  // referenced, not owned, not numbered yet
+          vert_stamp[size_t(w)] = -1;         // numbered halo (stamp reset; vert_local valid)
+          vert_local[size_t(w)] = next_local++;
+          halo.push_back(w);
+          plan.vert_gid.push_back(w);
+        }
+      }
+    // phase C: rows
+    const int32_t row_off = int32_t(plan.row_gstart.size());
+    const int32_t loff_off = int32_t(plan.row_loff.size());
+    int run = 0;
+    for (int l = 0; l < n_own; ++l) {
+      const int32_t g = owned[size_t(l)];
+      plan.row_gstart.push_back(int32_t(rowptr[g]));
+      plan.row_loff.push_back(uint16_t(run));
+      run += int(rowptr[g + 1] - rowptr[g]);
+    }
+    plan.row_loff.push_back(uint16_t(run));
+    // phase D: element records
+    const int32_t elem_off = int32_t(plan.records.size() / 3);
+    for (int32_t e : tile_elems) {
+      const I *c = conn + 3 * int64_t(e);
+      uint32_t word[3];
+      for (int j = 0; j < 3; ++j) {
+        const int32_t row = int32_t(c[j]);
+        word[j] = uint32_t(vert_local[size_t(row)]);
+        if (vert_stamp[size_t(row)] != -2 - tile) continue;  // row not owned here
+        const int32_t *first = colind + rowptr[row];
+        const int32_t *last = colind + rowptr[row + 1];
+        for (int i = 0; i < 3; ++i) {
+          const uint32_t pos = uint32_t(std::lower_bound(first, last, int32_t(c[i])) - first);
+          word[j] |= pos << (12 + 4 * i);
+        }
+      }
+      plan.records.insert(plan.records.end(), word, word + 3);
+    }
+    // un-own (so a later tile that references these vertices as halo numbers them afresh)
+    for (int32_t g : owned) vert_stamp[size_t(g)] = -1;
+    const int32_t d[8] = {elem_off, int32_t(tile_elems.size()), vert_off, next_local, n_own,
+                          row_off, run, loff_off};
+    plan.desc.insert(plan.desc.end(), d, d + 8);
+    plan.max_n_elem = std::max(plan.max_n_elem, d[1]);
+    plan.max_n_vert = std::max(plan.max_n_vert, d[3]);
+    plan.max_n_own = std::max(plan.max_n_own, d[4]);
+    plan.max_acc = std::max(plan.max_acc, d[6]);
+    ++tile;
+    // stamps of this tile's elements must not collide with the next tile id: they hold `tile-1`
+  }
+  plan.n_tiles = tile;
+  return TFEM_OK;
+}
+
+}  // namespace
+}  // namespace tfem
+
+extern "C" {
+
+int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                          const double *coords_host, const int64_t *rowptr_host,
+                          const int32_t *colind_host, int elem_cap, int vert_cap, int acc_cap,
+                          int own_cap, void **plan_out) {
+  using namespace tfem;
+  if (!plan_out) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_out is NULL");
+  *plan_out = nullptr;
+  if (idx_bytes != 4 && idx_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "idx_bytes must be 4 or 8");
+  if (n_elems < 0 || n_verts < 0 || (n_elems > 0 && !conn_host) || (n_verts > 0 && !coords_host) ||
+      !rowptr_host)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (elem_cap < 1 || vert_cap < 3 || vert_cap > 4096 || acc_cap < 16 || acc_cap > 65535 ||
+      own_cap < 1)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad tile capacities");
+  if (3 * n_elems >= (int64_t(1) << 31) || rowptr_host[n_verts] >= (int64_t(1) << 31))
+    return fail(TFEM_ERR_INDEX_RANGE, "mesh too large for the int32 tile plan");
+  auto *plan = new TilePlan();
+  int st;
+  if (idx_bytes == 4)
+    st = build(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host, rowptr_host,
+               colind_host, elem_cap, vert_cap, acc_cap, own_cap, *plan);
+  else
+    st = build(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host, rowptr_host,
+               colind_host, elem_cap, vert_cap, acc_cap, own_cap, *plan);
+  if (st != TFEM_OK) {
+    delete plan;
+    return st;
+  }
+  *plan_out = plan;
+  return TFEM_OK;
+}
+
+int tfem_tile_plan_sizes(const void *plan_handle, int64_t sizes[10]) {
+  using namespace tfem;
+  if (!plan_handle || !sizes) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const auto *p = static_cast<const TilePlan *>(plan_handle);
+  sizes[0] = p->n_tiles;
+  sizes[1] = int64_t(p->records.size() / 3);
+  sizes[2] = int64_t(p->vert_gid.size());
+  sizes[3] = int64_t(p->row_gstart.size());
+  sizes[4] = int64_t(p->row_loff.size());
+  sizes[5] = p->max_n_elem;
+  sizes[6] = p->max_n_vert;
+  sizes[7] = p->max_n_own;
+  sizes[8] = p->max_acc;
+  sizes[9] = p->max_row_len;
+  return TFEM_OK;
+}
+
+int tfem_tile_plan_export(const void *plan_handle, int32_t *desc, uint32_t *records,
+                          int32_t *vert_gid, int32_t *row_gstart, uint16_t *row_loff) {
+  using namespace tfem;
+  if (!plan_handle) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL plan");
+  const auto *p = static_cast<const TilePlan *>(plan_handle);
+  if (desc) std::memcpy(desc, p->desc.data(), p->desc.size() * sizeof(int32_t));
+  if (records) std::memcpy(records, p->records.data(), p->records.size() * sizeof(uint32_t));
+  if (vert_gid) std::memcpy(vert_gid, p->vert_gid.data(), p->vert_gid.size() * sizeof(int32_t));
+  if (row_gstart)
+    std::memcpy(row_gstart, p->row_gstart.data(), p->row_gstart.size() * sizeof(int32_t));
+  if (row_loff) std::memcpy(row_loff, p->row_loff.data(), p->row_loff.size() * sizeof(uint16_t));
+  return TFEM_OK;
+}
+
+void tfem_tile_plan_destroy(void *plan_handle) { delete static_cast<tfem::TilePlan *>(plan_handle); }
+
+}  // extern "C"

@@ -299,6 +299,31 @@ def test_p1_csr_against_oracle(n, order):
     assert scaled_error(f.cpu(), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
 
 
+@pytest.mark.parametrize("mesh_kind", ["structured", "delaunay", "delaunay_morton"])
+def test_tile_kernel_and_atomic_kernel_agree_with_oracle(mesh_kind):
+    from pytorch_fem_solver_amd import meshgen
+
+    if mesh_kind == "structured":
+        mesh_np = meshgen.unit_square(150, 0.25, 3)
+    else:
+        mesh_np = meshgen.delaunay_square(20000, 5)
+        if mesh_kind == "delaunay_morton":
+            mesh_np = meshgen.permute_mesh(mesh_np, vertex_order=meshgen.morton_order(mesh_np["vertices"]))
+    nv = mesh_np["vertices"].shape[0]
+    local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, "stiffness_mass")
+    _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    got = {}
+    for kernel in ("tiles", "atomic"):
+        basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+        basis._engine.kernel = kernel
+        K = basis.integrate_bilinear_form(stiffness_mass, layout="csr")
+        assert basis._engine.kernel_name() == f"k_p1_bilinear_{kernel}"
+        assert scaled_error(K.values.cpu(), want) <= TOL, kernel
+        got[kernel] = K.values
+    assert scaled_error(got["tiles"].cpu(), got["atomic"].cpu()) <= 1e-14
+
+
 def test_edge_cases_empty_and_single_element():
     mesh_np = {
         "vertices": np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 1.0]]),
