@@ -158,12 +158,16 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
  *   create : plan handle from connectivity, coordinates (for the curve) and the CSR
  *            pattern of tfem_csr_symbolic_*; capacities bound a tile's elements,
  *            local vertices, accumulator entries and owned rows.
- *   sizes  : [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows
- *            [4] n_row_loff [5] max elems/tile [6] max verts/tile [7] max owned/tile
- *            [8] max accumulator entries/tile [9] max row length
+ *   sizes  : [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows [4] n_runs
+ *            [5] max elems/tile [6] max verts/tile [7] max owned/tile
+ *            [8] max accumulator entries/tile [9] max row length [10] max runs/tile
+ *            [11] n_run_starts (= n_runs + n_tiles)
  *   export : copy the plan into caller-owned host arrays:
- *            desc int32 (8 per tile), records uint32 (3 per element record),
- *            vert_gid int32, row_gstart int32, row_loff uint16.
+ *            desc int32 (12 per tile), records uint32 (3 per element record),
+ *            vert_gid int32 [sizes[2]], row_loff uint16 [sizes[3]],
+ *            run_delta int32 [sizes[4]] (allocate one spare entry), run_lstart uint16
+ *            [sizes[11]].  An output run is a maximal group of owned rows that is
+ *            contiguous in the CSR value array.
  * The handle is internal library memory and must be released with _destroy.
  * ------------------------------------------------------------------------- */
 int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
@@ -171,20 +175,23 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                           const int64_t *rowptr_host, const int32_t *colind_host,
                           int elem_cap, int vert_cap, int acc_cap, int own_cap,
                           void **plan_out);
-int tfem_tile_plan_sizes(const void *plan, int64_t sizes[10]);
+int tfem_tile_plan_sizes(const void *plan, int64_t sizes[12]);
 int tfem_tile_plan_export(const void *plan, int32_t *desc, uint32_t *records,
-                          int32_t *vert_gid, int32_t *row_gstart, uint16_t *row_loff);
+                          int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
+                          uint16_t *run_lstart);
 void tfem_tile_plan_destroy(void *plan);
-/* Largest elem_cap the compiled kernel accepts. */
-int tfem_tile_elem_capacity(void);
+/* Largest capacity the compiled kernel accepts: what = 0 elements, 1 local vertices,
+ * 2 owned rows per tile. */
+int tfem_tile_capacity(int what);
 /* alpha * stiffness + beta * mass into CSR vals (every entry written once; vals need
  * not be initialised).  All plan arrays are DEVICE copies of the exported ones. */
 int tfem_p1_bilinear_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
                            double beta, const int32_t *desc, int64_t n_tiles,
                            const uint32_t *records, const int32_t *vert_gid,
-                           const int32_t *row_gstart, const uint16_t *row_loff,
-                           int max_n_elem, int max_n_vert, int max_n_own, int max_acc,
-                           void *vals, void *stream);
+                           const uint16_t *row_loff, const int32_t *run_delta,
+                           const uint16_t *run_lstart, int max_n_elem, int max_n_vert,
+                           int max_n_own, int max_acc, int max_n_runs, void *vals,
+                           void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,7 @@ def symbolic_host(conn_dof, n_dofs):
 
 #: default tile capacities: 45 KB of LDS per workgroup -> 3 workgroups per CU
 TILE_DEFAULTS = {"own": 512, "acc": 4096, "vert": 704}
+PLAN_ARRAYS = ("desc", "records", "vert_gid", "row_loff", "run_delta", "run_lstart")
 
 
 def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=None,
@@ -76,7 +77,9 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
     own_cap = own_cap or env("TFEM_TILE_OWN", TILE_DEFAULTS["own"])
     acc_cap = acc_cap or env("TFEM_TILE_ACC", TILE_DEFAULTS["acc"])
     vert_cap = vert_cap or env("TFEM_TILE_VERT", TILE_DEFAULTS["vert"])
-    elem_cap = elem_cap or lib.tfem_tile_elem_capacity()
+    elem_cap = min(elem_cap or 1 << 30, lib.tfem_tile_capacity(0))
+    vert_cap = min(vert_cap, lib.tfem_tile_capacity(1))
+    own_cap = min(own_cap, lib.tfem_tile_capacity(2))
     conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32)).reshape(-1, 3)
     coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
     rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
@@ -91,20 +94,18 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
         )
     )
     try:
-        sizes = np.zeros(10, dtype=np.int64)
+        sizes = np.zeros(12, dtype=np.int64)
         _native.check(lib.tfem_tile_plan_sizes(handle, c_void_p(sizes.ctypes.data)))
         plan = {
-            "desc": np.zeros(max(8 * sizes[0], 1), dtype=np.int32),
-            "records": np.zeros(max(3 * sizes[1], 1), dtype=np.uint32),
+            "desc": np.zeros(max(12 * sizes[0], 1), dtype=np.int32),
+            "records": np.zeros(max(3 * sizes[1], 3), dtype=np.uint32),
             "vert_gid": np.zeros(max(sizes[2], 1), dtype=np.int32),
-            "row_gstart": np.zeros(max(sizes[3], 1), dtype=np.int32),
-            "row_loff": np.zeros(max(sizes[4], 1), dtype=np.uint16),
+            "row_loff": np.zeros(max(sizes[3], 1), dtype=np.uint16),
+            "run_delta": np.zeros(sizes[4] + 1, dtype=np.int32),  # one spare entry
+            "run_lstart": np.zeros(max(sizes[11], 1), dtype=np.uint16),
         }
         _native.check(
-            lib.tfem_tile_plan_export(
-                handle, *[c_void_p(plan[k].ctypes.data)
-                          for k in ("desc", "records", "vert_gid", "row_gstart", "row_loff")]
-            )
+            lib.tfem_tile_plan_export(handle, *[c_void_p(plan[k].ctypes.data) for k in PLAN_ARRAYS])
         )
     finally:
         lib.tfem_tile_plan_destroy(handle)
@@ -224,7 +225,7 @@ class AssemblyEngine:
         """Name of the dominant numeric kernel as rocprofv3 reports it."""
         if self.poly_order != 1:
             return "k_p2_bilinear_atomic"
-        return "k_p1_bilinear_tiles" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
+        return "k_p1_tiles_pipe" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
 
     def wrap_csr(self, vals):
         rowptr, colind, _ = self.csr_structure()
@@ -274,8 +275,9 @@ class AssemblyEngine:
                         _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
                         float(beta), _native.ptr(tiles["desc"]), sz[0],
                         _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
-                        _native.ptr(tiles["row_gstart"]), _native.ptr(tiles["row_loff"]),
-                        sz[5], sz[6], sz[7], sz[8], _native.ptr(vals), self._stream(),
+                        _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
+                        _native.ptr(tiles["run_lstart"]),
+                        sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), self._stream(),
                     )
                 )
             return vals

@@ -5,8 +5,8 @@
 // on a tile border are processed by up to three tiles), accumulates the owned rows in LDS
 // and writes each CSR value exactly once with plain stores -- no global atomics, no
 // zero-fill of the value array, no second pass.  Everything the kernel needs per element
-// is one 12-byte record: the three tile-local vertex ids and, for each of the three rows,
-// the positions of the three columns inside that row.
+// is one 12-byte record: the three tile-local vertex ids (pre-scaled to LDS byte offsets)
+// and, for each of the three rows, the positions of the three columns inside that row.
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -16,16 +16,24 @@
 
 namespace tfem {
 
+constexpr int kDescStride = 12;
+
 struct TilePlan {
   // limits the kernel was compiled for
   int elem_cap = 0, vert_cap = 0, acc_cap = 0;
-  // per tile: elem_off, n_elem, vert_off, n_vert, n_own, row_off, acc_size, loff_off
+  // per tile (kDescStride ints): elem_off, n_elem, vert_off, n_vert, n_own, acc_size,
+  // loff_off, run_off, n_runs, lrun_off, 0, 0
   std::vector<int32_t> desc;
   std::vector<uint32_t> records;    // 3 words per tile element
   std::vector<int32_t> vert_gid;    // global vertex id of every tile-local vertex
-  std::vector<int32_t> row_gstart;  // rowptr[g] of every owned row
-  std::vector<uint16_t> row_loff;   // n_own + 1 accumulator offsets per tile
+  std::vector<uint16_t> row_loff;   // accumulator offset of every owned row
+  // Output runs: maximal groups of owned rows that are contiguous in the CSR value array.
+  // Accumulator entry s of run r goes to vals[s + run_delta[r]]; run r covers entries
+  // [run_lstart[r], run_lstart[r+1]) (one sentinel per tile).
+  std::vector<int32_t> run_delta;
+  std::vector<uint16_t> run_lstart;
   int32_t max_n_elem = 0, max_n_vert = 0, max_n_own = 0, max_acc = 0, max_row_len = 0;
+  int32_t max_n_runs = 0;
   int64_t n_tiles = 0;
 };
 
@@ -151,44 +159,55 @@ int build(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
           plan.vert_gid.push_back(w);
         }
       }
-    // phase C: rows
-    const int32_t row_off = int32_t(plan.row_gstart.size());
+    // phase C: rows and output runs
     const int32_t loff_off = int32_t(plan.row_loff.size());
+    const int32_t run_off = int32_t(plan.run_delta.size());
+    const int32_t lrun_off = int32_t(plan.run_lstart.size());
     int run = 0;
+    int64_t next_global = -1;
     for (int l = 0; l < n_own; ++l) {
       const int32_t g = owned[size_t(l)];
-      plan.row_gstart.push_back(int32_t(rowptr[g]));
+      const int len = int(rowptr[g + 1] - rowptr[g]);
       plan.row_loff.push_back(uint16_t(run));
-      run += int(rowptr[g + 1] - rowptr[g]);
+      if (len > 0 && rowptr[g] != next_global) {  // a new run starts at this row
+        plan.run_lstart.push_back(uint16_t(run));
+        plan.run_delta.push_back(int32_t(rowptr[g] - run));
+      }
+      if (len > 0) next_global = rowptr[g + 1];
+      run += len;
     }
-    plan.row_loff.push_back(uint16_t(run));
+    plan.run_lstart.push_back(uint16_t(run));
+    const int32_t n_runs = int32_t(plan.run_delta.size()) - run_off;
     // phase D: element records
     const int32_t elem_off = int32_t(plan.records.size() / 3);
     for (int32_t e : tile_elems) {
       const I *c = conn + 3 * int64_t(e);
+      // word j: bits 0-15 = 16 * local id of vertex j (the byte offset of its coordinates
+      // in LDS), bits 16+4i.. = position of column c[i] inside row c[j] (rows owned here)
       uint32_t word[3];
       for (int j = 0; j < 3; ++j) {
         const int32_t row = int32_t(c[j]);
-        word[j] = uint32_t(vert_local[size_t(row)]);
+        word[j] = uint32_t(vert_local[size_t(row)]) << 4;
         if (vert_stamp[size_t(row)] != -2 - tile) continue;  // row not owned here
         const int32_t *first = colind + rowptr[row];
         const int32_t *last = colind + rowptr[row + 1];
         for (int i = 0; i < 3; ++i) {
           const uint32_t pos = uint32_t(std::lower_bound(first, last, int32_t(c[i])) - first);
-          word[j] |= pos << (12 + 4 * i);
+          word[j] |= pos << (16 + 4 * i);
         }
       }
       plan.records.insert(plan.records.end(), word, word + 3);
     }
     // un-own (so a later tile that references these vertices as halo numbers them afresh)
     for (int32_t g : owned) vert_stamp[size_t(g)] = -1;
-    const int32_t d[8] = {elem_off, int32_t(tile_elems.size()), vert_off, next_local, n_own,
-                          row_off, run, loff_off};
-    plan.desc.insert(plan.desc.end(), d, d + 8);
+    const int32_t d[kDescStride] = {elem_off, int32_t(tile_elems.size()), vert_off, next_local,
+                                    n_own, run, loff_off, run_off, n_runs, lrun_off, 0, 0};
+    plan.desc.insert(plan.desc.end(), d, d + kDescStride);
     plan.max_n_elem = std::max(plan.max_n_elem, d[1]);
     plan.max_n_vert = std::max(plan.max_n_vert, d[3]);
     plan.max_n_own = std::max(plan.max_n_own, d[4]);
-    plan.max_acc = std::max(plan.max_acc, d[6]);
+    plan.max_acc = std::max(plan.max_acc, d[5]);
+    plan.max_n_runs = std::max(plan.max_n_runs, n_runs);
     ++tile;
     // stamps of this tile's elements must not collide with the next tile id: they hold `tile-1`
   }
@@ -234,34 +253,39 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
   return TFEM_OK;
 }
 
-int tfem_tile_plan_sizes(const void *plan_handle, int64_t sizes[10]) {
+int tfem_tile_plan_sizes(const void *plan_handle, int64_t sizes[12]) {
   using namespace tfem;
   if (!plan_handle || !sizes) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   const auto *p = static_cast<const TilePlan *>(plan_handle);
   sizes[0] = p->n_tiles;
   sizes[1] = int64_t(p->records.size() / 3);
   sizes[2] = int64_t(p->vert_gid.size());
-  sizes[3] = int64_t(p->row_gstart.size());
-  sizes[4] = int64_t(p->row_loff.size());
+  sizes[3] = int64_t(p->row_loff.size());
+  sizes[4] = int64_t(p->run_delta.size());
   sizes[5] = p->max_n_elem;
   sizes[6] = p->max_n_vert;
   sizes[7] = p->max_n_own;
   sizes[8] = p->max_acc;
   sizes[9] = p->max_row_len;
+  sizes[10] = p->max_n_runs;
+  sizes[11] = int64_t(p->run_lstart.size());
   return TFEM_OK;
 }
 
 int tfem_tile_plan_export(const void *plan_handle, int32_t *desc, uint32_t *records,
-                          int32_t *vert_gid, int32_t *row_gstart, uint16_t *row_loff) {
+                          int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
+                          uint16_t *run_lstart) {
   using namespace tfem;
   if (!plan_handle) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL plan");
   const auto *p = static_cast<const TilePlan *>(plan_handle);
   if (desc) std::memcpy(desc, p->desc.data(), p->desc.size() * sizeof(int32_t));
   if (records) std::memcpy(records, p->records.data(), p->records.size() * sizeof(uint32_t));
   if (vert_gid) std::memcpy(vert_gid, p->vert_gid.data(), p->vert_gid.size() * sizeof(int32_t));
-  if (row_gstart)
-    std::memcpy(row_gstart, p->row_gstart.data(), p->row_gstart.size() * sizeof(int32_t));
   if (row_loff) std::memcpy(row_loff, p->row_loff.data(), p->row_loff.size() * sizeof(uint16_t));
+  if (run_delta)
+    std::memcpy(run_delta, p->run_delta.data(), p->run_delta.size() * sizeof(int32_t));
+  if (run_lstart)
+    std::memcpy(run_lstart, p->run_lstart.data(), p->run_lstart.size() * sizeof(uint16_t));
   return TFEM_OK;
 }
 
