@@ -43,9 +43,11 @@ def parse():
     return p.parse_args()
 
 
-def algorithmic_bytes(n_elems, n_verts, nnz):
-    """conn 12 B/elem + each vertex once 16 B + each CSR value once 8 B."""
-    return 12 * n_elems + 16 * n_verts + 8 * nnz
+def algorithmic_bytes(n_elems, n_verts, nnz, with_load=True):
+    """conn 12 B/elem + each vertex once 16 B + each CSR value once 8 B for
+    K (48 B/element); + 8 B per vertex for f (its inputs are already counted): 52 B/element
+    for the fused K + f launch."""
+    return 12 * n_elems + 16 * n_verts + 8 * nnz + (8 * n_verts if with_load else 0)
 
 
 def cpu_baseline(n, order):
@@ -125,8 +127,7 @@ def main():
     exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine) if distributed else None
 
     def step():
-        vals = engine.bilinear(1.0, 0.0)
-        f = engine.load(fq)
+        vals, f = engine.assemble_system(1.0, 0.0, fq)  # one fused launch: K and f
         if exchange is not None:
             exchange.reduce(vals, f)
         return vals, f
@@ -145,9 +146,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         starts[i].record()
-        vals = engine.bilinear(1.0, 0.0)
+        vals, f = engine.assemble_system(1.0, 0.0, fq)
         ends[i].record()
-        f = engine.load(fq)
         if exchange is not None:
             exchange.reduce(vals, f)
     barrier()

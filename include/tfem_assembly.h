@@ -166,8 +166,9 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
  *            desc int32 (12 per tile), records uint32 (3 per element record),
  *            vert_gid int32 [sizes[2]], row_loff uint16 [sizes[3]],
  *            run_delta int32 [sizes[4]] (allocate one spare entry), run_lstart uint16
- *            [sizes[11]].  An output run is a maximal group of owned rows that is
- *            contiguous in the CSR value array.
+ *            [sizes[11]], elem_id int32 [sizes[1]] (original element of every record).
+ *            An output run is a maximal group of owned rows that is contiguous in the
+ *            CSR value array.
  * The handle is internal library memory and must be released with _destroy.
  * ------------------------------------------------------------------------- */
 int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
@@ -178,19 +179,25 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
 int tfem_tile_plan_sizes(const void *plan, int64_t sizes[12]);
 int tfem_tile_plan_export(const void *plan, int32_t *desc, uint32_t *records,
                           int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
-                          uint16_t *run_lstart);
+                          uint16_t *run_lstart, int32_t *elem_id);
 void tfem_tile_plan_destroy(void *plan);
 /* Largest capacity the compiled kernel accepts: what = 0 elements, 1 local vertices,
- * 2 owned rows per tile. */
+ * 2 owned rows, 3 accumulator entries per tile. */
 int tfem_tile_capacity(int what);
-/* alpha * stiffness + beta * mass into CSR vals (every entry written once; vals need
- * not be initialised).  All plan arrays are DEVICE copies of the exported ones. */
-int tfem_p1_bilinear_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
+/* One launch over the tile plan (all plan arrays are DEVICE copies of the exported ones):
+ *   vals != NULL : CSR values of alpha * stiffness + beta * mass (every entry written
+ *                  once; vals need not be initialised)        [abstract_basis.py:74-93]
+ *   fq   != NULL : load vector fout[n_verts] = sum_e sum_q fq[e][q] phi_i(x_q) dx_q from
+ *                  the user's source values fq (n_elems, Q) in ORIGINAL element order
+ *                  (every entry written once)                 [abstract_basis.py:95-112]
+ * Either or both. */
+int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
                            double beta, const int32_t *desc, int64_t n_tiles,
                            const uint32_t *records, const int32_t *vert_gid,
                            const uint16_t *row_loff, const int32_t *run_delta,
-                           const uint16_t *run_lstart, int max_n_elem, int max_n_vert,
-                           int max_n_own, int max_acc, int max_n_runs, void *vals,
+                           const uint16_t *run_lstart, const int32_t *elem_id,
+                           int max_n_elem, int max_n_vert, int max_n_own, int max_acc,
+                           int max_n_runs, void *vals, const void *fq, void *fout,
                            void *stream);
 
 #ifdef __cplusplus

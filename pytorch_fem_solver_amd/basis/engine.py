@@ -64,7 +64,7 @@ def symbolic_host(conn_dof, n_dofs):
 
 #: default tile capacities: 45 KB of LDS per workgroup -> 3 workgroups per CU
 TILE_DEFAULTS = {"own": 512, "acc": 4096, "vert": 704}
-PLAN_ARRAYS = ("desc", "records", "vert_gid", "row_loff", "run_delta", "run_lstart")
+PLAN_ARRAYS = ("desc", "records", "vert_gid", "row_loff", "run_delta", "run_lstart", "elem_id")
 
 
 def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=None,
@@ -103,6 +103,7 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
             "row_loff": np.zeros(max(sizes[3], 1), dtype=np.uint16),
             "run_delta": np.zeros(sizes[4] + 1, dtype=np.int32),  # one spare entry
             "run_lstart": np.zeros(max(sizes[11], 1), dtype=np.uint16),
+            "elem_id": np.zeros(max(sizes[1], 1), dtype=np.int32),
         }
         _native.check(
             lib.tfem_tile_plan_export(handle, *[c_void_p(plan[k].ctypes.data) for k in PLAN_ARRAYS])
@@ -264,23 +265,8 @@ class AssemblyEngine:
     def bilinear(self, alpha: float, beta: float):
         """CSR values of alpha*stiffness + beta*mass (fused kernel)."""
         d = self._inputs()
-        tiles = self.tile_plan()
-        if tiles is not None:
-            sz = tiles["sizes"]
-            vals = torch.empty(int(self.csr_structure()[1].shape[0]), dtype=self.dtype,
-                               device=self.device)
-            with torch.cuda.device(self.device):
-                _native.check(
-                    self.lib.tfem_p1_bilinear_tiles(
-                        _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
-                        float(beta), _native.ptr(tiles["desc"]), sz[0],
-                        _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
-                        _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
-                        _native.ptr(tiles["run_lstart"]),
-                        sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), self._stream(),
-                    )
-                )
-            return vals
+        if self.tile_plan() is not None:
+            return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
         _, colind, slots = self.csr_structure()
         nnz = int(colind.shape[0])
         vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
@@ -296,8 +282,43 @@ class AssemblyEngine:
             )
         return vals
 
+    def _assemble_tiles(self, alpha, beta, want_matrix, fq):
+        """One tfem_p1_assemble_tiles launch: CSR values and/or the load vector."""
+        d = self._inputs()
+        tiles = self.tile_plan()
+        sz = tiles["sizes"]
+        vals = fout = None
+        if want_matrix:
+            vals = torch.empty(int(self.csr_structure()[1].shape[0]), dtype=self.dtype,
+                               device=self.device)
+        if fq is not None:
+            fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
+            fout = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self.lib.tfem_p1_assemble_tiles(
+                    _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
+                    float(beta), _native.ptr(tiles["desc"]), sz[0],
+                    _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
+                    _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
+                    _native.ptr(tiles["run_lstart"]), _native.ptr(tiles["elem_id"]),
+                    sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), _native.ptr(fq),
+                    _native.ptr(fout), self._stream(),
+                )
+            )
+        return vals, fout
+
+    def assemble_system(self, alpha, beta, fq):
+        """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
+        values fq (E, Q): one fused launch on the tile path, two launches otherwise."""
+        if self.tile_plan() is not None:
+            return self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
+        return self.bilinear(alpha, beta), self.load(fq)
+
     def load(self, fq):
         """(N_dof,) vector of sum_q f_q phi_i dx_q; fq is (E, Q) on any device."""
+        if self.tile_plan() is not None:
+            return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]
         d = self._inputs()
         fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
         out = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)

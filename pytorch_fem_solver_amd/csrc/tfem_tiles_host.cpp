@@ -25,6 +25,7 @@ struct TilePlan {
   // loff_off, run_off, n_runs, lrun_off, 0, 0
   std::vector<int32_t> desc;
   std::vector<uint32_t> records;    // 3 words per tile element
+  std::vector<int32_t> elem_id;     // original element id of every record (load vector path)
   std::vector<int32_t> vert_gid;    // global vertex id of every tile-local vertex
   std::vector<uint16_t> row_loff;   // accumulator offset of every owned row
   // Output runs: maximal groups of owned rows that are contiguous in the CSR value array.
@@ -197,6 +198,7 @@ int build(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
         }
       }
       plan.records.insert(plan.records.end(), word, word + 3);
+      plan.elem_id.push_back(e);
     }
     // un-own (so a later tile that references these vertices as halo numbers them afresh)
     for (int32_t g : owned) vert_stamp[size_t(g)] = -1;
@@ -274,7 +276,7 @@ int tfem_tile_plan_sizes(const void *plan_handle, int64_t sizes[12]) {
 
 int tfem_tile_plan_export(const void *plan_handle, int32_t *desc, uint32_t *records,
                           int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
-                          uint16_t *run_lstart) {
+                          uint16_t *run_lstart, int32_t *elem_id) {
   using namespace tfem;
   if (!plan_handle) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL plan");
   const auto *p = static_cast<const TilePlan *>(plan_handle);
@@ -286,6 +288,7 @@ int tfem_tile_plan_export(const void *plan_handle, int32_t *desc, uint32_t *reco
     std::memcpy(run_delta, p->run_delta.data(), p->run_delta.size() * sizeof(int32_t));
   if (run_lstart)
     std::memcpy(run_lstart, p->run_lstart.data(), p->run_lstart.size() * sizeof(uint16_t));
+  if (elem_id) std::memcpy(elem_id, p->elem_id.data(), p->elem_id.size() * sizeof(int32_t));
   return TFEM_OK;
 }
 

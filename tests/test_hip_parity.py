@@ -324,6 +324,31 @@ def test_tile_kernel_and_atomic_kernel_agree_with_oracle(mesh_kind):
     assert scaled_error(got["tiles"].cpu(), got["atomic"].cpu()) <= 1e-14
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_fused_system_launch_matches_separate_forms(order):
+    """engine.assemble_system = one tile-kernel launch for K and f (bench.py's step)."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.delaunay_square(6000, 11)
+    nv = mesh_np["vertices"].shape[0]
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, order))
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    fq = rhs(x, y).reshape(-1, basis._engine.n_quad)
+    vals, f = basis._engine.assemble_system(1.0, 1.0, fq)
+    assert basis._engine.kernel_name() == "k_p1_tiles_pipe"
+    local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "stiffness_mass")
+    _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
+    assert scaled_error(vals.cpu(), orc.assemble_csr_values(local, slots, colind.shape[0])) <= TOL
+    fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "load")
+    assert scaled_error(f.cpu().reshape(-1, 1), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
+    # the load-only launch and the strict-order atomic kernels agree too
+    f_only = basis._engine.load(fq)
+    assert scaled_error(f_only.cpu(), f.cpu()) <= 1e-14
+    basis2 = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, order))
+    basis2._engine.kernel = "atomic"
+    assert scaled_error(basis2._engine.load(fq).cpu(), f.cpu()) <= 1e-13
+
+
 def test_edge_cases_empty_and_single_element():
     mesh_np = {
         "vertices": np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 1.0]]),

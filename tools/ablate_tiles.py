@@ -22,6 +22,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--n", type=int, default=2236)
 p.add_argument("--reps", type=int, default=20)
 p.add_argument("--variants", default="1")
+p.add_argument("--load", action="store_true", help="fused K + load vector")
 args = p.parse_args()
 
 torch.set_default_dtype(torch.float64)
@@ -36,19 +37,31 @@ nnz = int(eng.csr_structure()[1].shape[0])
 vals = torch.empty(nnz)
 stamps = torch.zeros(8 * 4 * 4096, dtype=torch.int64)
 lib = _native.load()
-fn = lib.tfem_p1_bilinear_tiles_debug
+fn = lib.tfem_p1_tiles_debug
 fn.restype = ctypes.c_int
 ne = mesh_np["triangles"].shape[0]
 print(f"elements {ne}, tiles {sz[0]}, records/elem {sz[1]/ne:.3f}, plan sizes {sz}")
+
+
+p_load = args.load
+fq = None
+fout = None
+if p_load:
+    import math
+    pts = eng.geometry()[2]
+    fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
+    fout = torch.empty(eng.n_dofs)
+    del pts
 
 
 def run(flags, variant):
     _native.check(fn(_native.ptr(d["coords"]), 3, _native.ptr(tiles["desc"]), ctypes.c_int64(sz[0]),
                      _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
                      _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
-                     _native.ptr(tiles["run_lstart"]),
-                     sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals),
-                     _native.current_stream(eng.device), flags, _native.ptr(stamps)))
+                     _native.ptr(tiles["run_lstart"]), _native.ptr(tiles["elem_id"]),
+                     sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), _native.ptr(fq),
+                     _native.ptr(fout), _native.current_stream(eng.device), flags,
+                     _native.ptr(stamps)))
 
 
 CASES = (("full", 0), ("no atomics", 1), ("no element phase", 2), ("no stores", 4),
@@ -57,7 +70,7 @@ CASES = (("full", 0), ("no atomics", 1), ("no element phase", 2), ("no stores", 
          ("no gather+no stores", 12))
 
 for variant in [int(v) for v in args.variants.split(",")]:
-    print("k_p1_tiles_pipe (persistent, pipelined)")
+    print("k_p1_tiles_pipe (persistent, pipelined)", "K + f" if p_load else "K only")
     for name, flags in CASES:
         for _ in range(3):
             run(flags, variant)
