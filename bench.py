@@ -35,11 +35,12 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
+    p.add_argument("--grid", dest="n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
     p.add_argument("--order", type=int, default=3, help="integration order")
     p.add_argument("--cpu-sample", type=int, default=707, help="n of the CPU-baseline sample mesh")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | atomic | tiles")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     return p.parse_args()
 
 
@@ -105,17 +106,23 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsals share one card
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import pytorch_fem_solver_amd as tf
     from pytorch_fem_solver_amd import meshgen, parallel
 
+    if args.kernel != "auto":
+        os.environ["TFEM_KERNEL"] = args.kernel
     torch.set_default_dtype(torch.float64)
     n = args.n
     # rank r owns the strip [r, r+1] x [0, 1]; identical jitter pattern per strip so that

@@ -158,17 +158,19 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
  *   create : plan handle from connectivity, coordinates (for the curve) and the CSR
  *            pattern of tfem_csr_symbolic_*; capacities bound a tile's elements,
  *            local vertices, accumulator entries and owned rows.
- *   sizes  : [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows [4] n_runs
+ *   sizes  : fills layout[20]:
+ *            [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows [4] n_runs
  *            [5] max elems/tile [6] max verts/tile [7] max owned/tile
  *            [8] max accumulator entries/tile [9] max row length [10] max runs/tile
  *            [11] n_run_starts (= n_runs + n_tiles)
- *   export : copy the plan into caller-owned host arrays:
- *            desc int32 (12 per tile), records uint32 (3 per element record),
- *            vert_gid int32 [sizes[2]], row_loff uint16 [sizes[3]],
- *            run_delta int32 [sizes[4]] (allocate one spare entry), run_lstart uint16
- *            [sizes[11]], elem_id int32 [sizes[1]] (original element of every record).
- *            An output run is a maximal group of owned rows that is contiguous in the
- *            CSR value array.
+ *            [12..18] byte offsets of desc, records, vert_gid, row_loff, run_delta,
+ *            run_lstart, elem_id inside the packed plan; [19] bytes of the packed plan
+ *   pack   : write the packed plan (layout[19] bytes, caller-owned HOST memory):
+ *            desc int32 (12 per tile) | records uint32 (3 per element record: 16 * local
+ *            vertex id | 4-bit column positions << 16) | vert_gid int32 | row_loff uint16 |
+ *            run_delta int32 | run_lstart uint16 | elem_id int32 (original element of every
+ *            record).  An output run is a maximal group of owned rows that is contiguous in
+ *            the CSR value array.  The caller copies the blob to the device once.
  * The handle is internal library memory and must be released with _destroy.
  * ------------------------------------------------------------------------- */
 int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
@@ -176,29 +178,25 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                           const int64_t *rowptr_host, const int32_t *colind_host,
                           int elem_cap, int vert_cap, int acc_cap, int own_cap,
                           void **plan_out);
-int tfem_tile_plan_sizes(const void *plan, int64_t sizes[12]);
-int tfem_tile_plan_export(const void *plan, int32_t *desc, uint32_t *records,
-                          int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
-                          uint16_t *run_lstart, int32_t *elem_id);
+int tfem_tile_plan_sizes(const void *plan, int64_t layout[20]);
+int tfem_tile_plan_pack(const void *plan, void *blob_host);
 void tfem_tile_plan_destroy(void *plan);
 /* Largest capacity the compiled kernel accepts: what = 0 elements, 1 local vertices,
  * 2 owned rows, 3 accumulator entries per tile. */
 int tfem_tile_capacity(int what);
-/* One launch over the tile plan (all plan arrays are DEVICE copies of the exported ones):
+/* One launch over the tile plan (`plan_device` = DEVICE copy of the packed plan,
+ * `plan_layout_host` = the HOST layout[20] of tfem_tile_plan_sizes):
  *   vals != NULL : CSR values of alpha * stiffness + beta * mass (every entry written
  *                  once; vals need not be initialised)        [abstract_basis.py:74-93]
  *   fq   != NULL : load vector fout[n_verts] = sum_e sum_q fq[e][q] phi_i(x_q) dx_q from
  *                  the user's source values fq (n_elems, Q) in ORIGINAL element order
  *                  (every entry written once)                 [abstract_basis.py:95-112]
- * Either or both. */
-int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
-                           double beta, const int32_t *desc, int64_t n_tiles,
-                           const uint32_t *records, const int32_t *vert_gid,
-                           const uint16_t *row_loff, const int32_t *run_delta,
-                           const uint16_t *run_lstart, const int32_t *elem_id,
-                           int max_n_elem, int max_n_vert, int max_n_own, int max_acc,
-                           int max_n_runs, void *vals, const void *fq, void *fout,
-                           void *stream);
+ * Either or both.  The kernel addresses every array through range-checked buffer
+ * resources (each array must stay below 4 GiB). */
+int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                           double alpha, double beta, const void *plan_device,
+                           const int64_t *plan_layout_host, void *vals, int64_t nnz,
+                           const void *fq, int64_t n_elems, void *fout, void *stream);
 
 #ifdef __cplusplus
 }

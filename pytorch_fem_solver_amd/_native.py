@@ -67,14 +67,13 @@ SIGNATURES = {
          c_int, c_void_p],
     ),
     "tfem_tile_plan_sizes": (c_int, [c_void_p, c_void_p]),
-    "tfem_tile_plan_export": (c_int, [c_void_p] * 8),
+    "tfem_tile_plan_pack": (c_int, [c_void_p, c_void_p]),
     "tfem_tile_plan_destroy": (None, [c_void_p]),
     "tfem_tile_capacity": (c_int, [c_int]),
     "tfem_p1_assemble_tiles": (
         c_int,
-        [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_int64, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-         c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
+         c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "tfem_csr_to_dense": (
         c_int,

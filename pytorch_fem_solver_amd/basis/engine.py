@@ -64,7 +64,6 @@ def symbolic_host(conn_dof, n_dofs):
 
 #: default tile capacities: 45 KB of LDS per workgroup -> 3 workgroups per CU
 TILE_DEFAULTS = {"own": 512, "acc": 4096, "vert": 704}
-PLAN_ARRAYS = ("desc", "records", "vert_gid", "row_loff", "run_delta", "run_lstart", "elem_id")
 
 
 def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=None,
@@ -94,24 +93,34 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
         )
     )
     try:
-        sizes = np.zeros(12, dtype=np.int64)
-        _native.check(lib.tfem_tile_plan_sizes(handle, c_void_p(sizes.ctypes.data)))
-        plan = {
-            "desc": np.zeros(max(12 * sizes[0], 1), dtype=np.int32),
-            "records": np.zeros(max(3 * sizes[1], 3), dtype=np.uint32),
-            "vert_gid": np.zeros(max(sizes[2], 1), dtype=np.int32),
-            "row_loff": np.zeros(max(sizes[3], 1), dtype=np.uint16),
-            "run_delta": np.zeros(sizes[4] + 1, dtype=np.int32),  # one spare entry
-            "run_lstart": np.zeros(max(sizes[11], 1), dtype=np.uint16),
-            "elem_id": np.zeros(max(sizes[1], 1), dtype=np.int32),
-        }
-        _native.check(
-            lib.tfem_tile_plan_export(handle, *[c_void_p(plan[k].ctypes.data) for k in PLAN_ARRAYS])
-        )
+        layout = np.zeros(20, dtype=np.int64)
+        _native.check(lib.tfem_tile_plan_sizes(handle, c_void_p(layout.ctypes.data)))
+        blob = np.zeros(int(layout[19]), dtype=np.uint8)
+        _native.check(lib.tfem_tile_plan_pack(handle, c_void_p(blob.ctypes.data)))
     finally:
         lib.tfem_tile_plan_destroy(handle)
-    plan["sizes"] = sizes
-    return plan
+    return unpack_plan(blob, layout)
+
+
+def unpack_plan(blob, layout):
+    """Views of the packed plan's arrays (host) + the blob and layout themselves."""
+    z = [int(x) for x in layout]
+
+    def view(i, dtype, count):
+        return np.frombuffer(blob, dtype=dtype, count=count, offset=z[12 + i])
+
+    return {
+        "blob": blob,
+        "layout": np.ascontiguousarray(layout, dtype=np.int64),
+        "sizes": np.asarray(layout[:12]),
+        "desc": view(0, np.int32, 12 * z[0]),
+        "records": view(1, np.uint32, 3 * z[1]),
+        "vert_gid": view(2, np.int32, z[2]),
+        "row_loff": view(3, np.uint16, z[3]),
+        "run_delta": view(4, np.int32, z[4]),
+        "run_lstart": view(5, np.uint16, z[11]),
+        "elem_id": view(6, np.int32, z[1]),
+    }
 
 
 class AssemblyEngine:
@@ -211,13 +220,11 @@ class AssemblyEngine:
                 except NotImplementedError:
                     plan = None
                 if plan is not None:
-                    dev = self.device
                     self._tiles = {
-                        k: torch.from_numpy(v.view(np.int32) if v.dtype == np.uint32 else
-                                            (v.view(np.int16) if v.dtype == np.uint16 else v)).to(dev)
-                        for k, v in plan.items() if k != "sizes"
+                        "blob": torch.from_numpy(plan["blob"]).to(self.device),
+                        "layout": plan["layout"],
+                        "sizes": [int(x) for x in plan["sizes"]],
                     }
-                    self._tiles["sizes"] = [int(x) for x in plan["sizes"]]
             if self._tiles is False and self.kernel == "tiles":
                 raise NotImplementedError("the tile-plan kernel does not apply to this basis")
         return self._tiles or None
@@ -286,7 +293,6 @@ class AssemblyEngine:
         """One tfem_p1_assemble_tiles launch: CSR values and/or the load vector."""
         d = self._inputs()
         tiles = self.tile_plan()
-        sz = tiles["sizes"]
         vals = fout = None
         if want_matrix:
             vals = torch.empty(int(self.csr_structure()[1].shape[0]), dtype=self.dtype,
@@ -294,16 +300,14 @@ class AssemblyEngine:
         if fq is not None:
             fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
             fout = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+        nnz = int(vals.shape[0]) if vals is not None else 0
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_p1_assemble_tiles(
-                    _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
-                    float(beta), _native.ptr(tiles["desc"]), sz[0],
-                    _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
-                    _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
-                    _native.ptr(tiles["run_lstart"]), _native.ptr(tiles["elem_id"]),
-                    sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), _native.ptr(fq),
-                    _native.ptr(fout), self._stream(),
+                    _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
+                    float(alpha), float(beta), _native.ptr(tiles["blob"]),
+                    c_void_p(tiles["layout"].ctypes.data), _native.ptr(vals), nnz,
+                    _native.ptr(fq), self.n_elems, _native.ptr(fout), self._stream(),
                 )
             )
         return vals, fout

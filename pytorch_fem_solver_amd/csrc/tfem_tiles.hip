@@ -51,26 +51,78 @@ constexpr int kElemPerLane = 2;  // tile element capacity   = 1024: two full rou
 constexpr int kVertPerLane = 2;  // tile vertex capacity    = 1024
 constexpr int kRowPerLane = 1;   // tile owned-row capacity = 512
 constexpr int kAccPerLane = 8;   // tile accumulator capacity = 4096 entries
-constexpr int kChunks = kTileBlock * kAccPerLane / 64;  // 64-entry output chunks per tile
+constexpr int kChunkLen = 128;   // accumulator entries per output chunk: two per lane
+constexpr int kChunks = kTileBlock * kAccPerLane / kChunkLen;
 constexpr int kDescStride = 12;  // ints per tile descriptor (tfem_tiles_host.cpp)
 // Accumulator entries behind lds_acc that absorb the rows a tile does not own; halo vertex l
 // uses entries (l & 15) .. (l & 15) + 15 so that neighbouring lanes do not pile up on one
 // address.
 constexpr int kTrash = 32;
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+// Buffer resource over `bytes` bytes at p: loads beyond the range return 0 and stores are
+// dropped by the hardware, so the tile kernel needs no index clamps, does its address
+// arithmetic in 32 bits and cannot fault on a damaged plan.  (Every array of the path is
+// far below 4 GiB; launch_tiles checks.)
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, int(bytes), 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ void buf_load2(rsrc_t r, unsigned off, T &x, T &y) {
+  if constexpr (sizeof(T) == 8) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    x = __builtin_bit_cast(double, u32x2{v.x, v.y});
+    y = __builtin_bit_cast(double, u32x2{v.z, v.w});
+  } else {
+    // NB: __builtin_amdgcn_raw_buffer_load_b64 is miscompiled by this hipcc (ROCm 7.2): it
+    // emits buffer_load_dword and leaves the second dword undefined.  Two dword loads.
+    x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off + 4u, 0, 0));
+  }
+}
+template <typename T>
+__device__ __forceinline__ T buf_load1(rsrc_t r, unsigned off) {
+  if constexpr (sizeof(T) == 8) {  // two dword loads: see buf_load2
+    const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+    const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(r, off + 4u, 0, 0);
+    return __builtin_bit_cast(double, u32x2{lo, hi});
+  } else {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void buf_store1(rsrc_t r, unsigned off, T x) {
+  if constexpr (sizeof(T) == 8)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, off, 0, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, off, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ void buf_store2(rsrc_t r, unsigned off, T x, T y) {
+  if constexpr (sizeof(T) == 8) {
+    const u32x2 a = __builtin_bit_cast(u32x2, x), b = __builtin_bit_cast(u32x2, y);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, b.x, b.y}, r, off, 0, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b64(
+        u32x2{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, off, 0, 0);
+  }
+}
+
 template <typename T>
 struct TileArgs {
   const T *coords;
-  const int32_t *desc;
-  const uint32_t *records;
-  const int32_t *vert_gid;
-  const uint16_t *row_loff;
-  const int32_t *run_delta;
-  const uint16_t *run_lstart;
-  const int32_t *elem_id;  // load vector only
+  const int32_t *desc;     // = plan + off_desc
+  const unsigned char *plan;  // packed plan (tfem_tile_plan_pack)
   const T *fq;             // (n_elems, Q) source values, load vector only
   T *vals;
   T *fout;
+  // array extents in bytes (buffer resources)
+  unsigned coords_bytes, plan_bytes, fq_bytes, vals_bytes, fout_bytes;
+  unsigned off_rec, off_gid, off_loff, off_rund, off_runl, off_eid;  // byte offsets inside plan
   int n_tiles;
   int lds_acc;   // accumulator entries reserved in LDS
   int lds_vert;  // vertex slots reserved in LDS
@@ -208,7 +260,7 @@ __device__ __forceinline__ void element_to_lds(const TileArgs<T> &a, const uint3
 // path never uses it.
 // ---------------------------------------------------------------------------------------
 template <typename T, bool KMAT, bool MASS, int QL, bool DBG>
-__global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<T> a) {
+__global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(const TileArgs<T> a) {
   constexpr bool LOAD = QL > 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *acc = reinterpret_cast<T *>(smem_raw);        // [lds_acc] + trash [kTrash] + facc [lds_own]
@@ -235,10 +287,12 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
     const int t = xcd * per + j;
     return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
   };
-  auto clamp_lane = [&](int slot, int count) {  // slot-th item of this lane, clamped
-    const int l = tid + slot * kTileBlock;
-    return l < count ? l : count - 1;
-  };
+  const rsrc_t r_coords = make_rsrc(a.coords, a.coords_bytes);
+  // all plan arrays live in ONE allocation (tfem_tile_plan_pack): one resource, five offsets
+  const rsrc_t r_plan = make_rsrc(a.plan, a.plan_bytes);
+  const rsrc_t r_fq = make_rsrc(a.fq, a.fq_bytes);
+  const rsrc_t r_vals = make_rsrc(a.vals, a.vals_bytes);
+  const rsrc_t r_fout = make_rsrc(a.fout, a.fout_bytes);
 
   // registers written by loads (S4) and read right after the vmcnt(0) of the next iteration
   uint32_t rec_ld[kElemPerLane][3];
@@ -251,58 +305,50 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
   uint32_t rec[kElemPerLane][3];
   T srcw[kElemPerLane][3];
 
+  // Lanes past the end of a tile read the next tile's entries (or 0 past the array); what
+  // they load is never used (null records, l < n_vert / n_own guards when parking).
   auto load_ids = [&](const TileDesc &d) {
 #pragma unroll
     for (int v = 0; v < kVertPerLane; ++v)
-      gid[v] = a.vert_gid[d.vert_off + clamp_lane(v, d.n_vert)];
+      gid[v] = int(__builtin_amdgcn_raw_buffer_load_b32(
+          r_plan, a.off_gid + unsigned(d.vert_off + tid + v * kTileBlock) * 4u, 0, 0));
     if (LOAD) {
 #pragma unroll
       for (int e = 0; e < kElemPerLane; ++e)
-        eid[e] = a.elem_id[d.elem_off + clamp_lane(e, d.n_elem > 0 ? d.n_elem : 1)];
+        eid[e] = int(__builtin_amdgcn_raw_buffer_load_b32(
+            r_plan, a.off_eid + unsigned(d.elem_off + tid + e * kTileBlock) * 4u, 0, 0));
     }
   };
   // `tile_slot` = k mod 3 of the tile being loaded: its owned vertex ids go to that LDS slot
   auto load_tile = [&](const TileDesc &d, int tile_slot) {
-    if (KMAT) {
 #pragma unroll
-      for (int e = 0; e < kElemPerLane; ++e) {
-        const int idx = clamp_lane(e, d.n_elem > 0 ? d.n_elem : 1);
-        const uint32_t *r = a.records + 3 * size_t(d.elem_off + idx);
-        rec_ld[e][0] = r[0];
-        rec_ld[e][1] = r[1];
-        rec_ld[e][2] = r[2];
-      }
-    } else {  // load vector only: the vertex ids of the records are enough
-#pragma unroll
-      for (int e = 0; e < kElemPerLane; ++e) {
-        const int idx = clamp_lane(e, d.n_elem > 0 ? d.n_elem : 1);
-        const uint32_t *r = a.records + 3 * size_t(d.elem_off + idx);
-        rec_ld[e][0] = r[0];
-        rec_ld[e][1] = r[1];
-        rec_ld[e][2] = r[2];
-      }
+    for (int e = 0; e < kElemPerLane; ++e) {
+      const u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(
+          r_plan, a.off_rec + unsigned(d.elem_off + tid + e * kTileBlock) * 12u, 0, 0);
+      rec_ld[e][0] = r.x;
+      rec_ld[e][1] = r.y;
+      rec_ld[e][2] = r.z;
     }
 #pragma unroll
     for (int r = 0; r < kRowPerLane; ++r) {
-      loff_ld[r] = a.row_loff[d.loff_off + clamp_lane(r, d.n_own)];
-      const int lr = clamp_lane(r, d.n_runs > 0 ? d.n_runs : 1);  // arrays are padded by one
-      runl_ld[r] = a.run_lstart[d.lrun_off + lr];
-      rund_ld[r] = a.run_delta[d.run_off + lr];
+      const unsigned l = unsigned(tid + r * kTileBlock);
+      loff_ld[r] = int(__builtin_amdgcn_raw_buffer_load_b16(r_plan, a.off_loff + (unsigned(d.loff_off) + l) * 2u, 0, 0));
+      runl_ld[r] = int(__builtin_amdgcn_raw_buffer_load_b16(r_plan, a.off_runl + (unsigned(d.lrun_off) + l) * 2u, 0, 0));
+      rund_ld[r] = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rund + (unsigned(d.run_off) + l) * 4u, 0, 0));
     }
     if (!(DBG && (a.flags & 8))) {
 #pragma unroll
-      for (int v = 0; v < kVertPerLane; ++v) {
-        const int64_t g = gid[v];
-        xy_ld[v][0] = a.coords[2 * g];
-        xy_ld[v][1] = a.coords[2 * g + 1];
-      }
+      for (int v = 0; v < kVertPerLane; ++v)
+        buf_load2<T>(r_coords, unsigned(gid[v]) * unsigned(2 * sizeof(T)), xy_ld[v][0], xy_ld[v][1]);
     }
     if (LOAD) {
 #pragma unroll
       for (int e = 0; e < kElemPerLane; ++e) {
-        const T *p = a.fq + size_t(eid[e]) * (QL > 0 ? QL : 1);
+        const unsigned base = unsigned(eid[e]) * unsigned((QL > 0 ? QL : 1) * sizeof(T));
 #pragma unroll
-        for (int q = 0; q < QL; ++q) fq_ld[e][q] = p[q];
+        for (int q = 0; q + 1 < QL; q += 2)
+          buf_load2<T>(r_fq, base + unsigned(q * sizeof(T)), fq_ld[e][q], fq_ld[e][q + 1]);
+        if (QL & 1) fq_ld[e][QL > 0 ? QL - 1 : 0] = buf_load1<T>(r_fq, base + unsigned((QL - 1) * sizeof(T)));
       }
       int *gid_w = gid_buf + tile_slot * a.lds_own;  // owned rows come first in the id list
 #pragma unroll
@@ -346,22 +392,25 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
     int *rund_w = rund_buf + run_buf * a.lds_run;
 #pragma unroll
     for (int r = 0; r < kRowPerLane; ++r) {
-      const int lr = clamp_lane(r, d.n_runs > 0 ? d.n_runs : 1);
-      runl_w[lr] = runl_ld[r];
-      rund_w[lr] = rund_ld[r];
+      const int lr = tid + r * kTileBlock;
+      if (lr < d.n_runs) {
+        runl_w[lr] = runl_ld[r];
+        rund_w[lr] = rund_ld[r];
+      }
     }
     if (tid == 0) runl_w[d.n_runs] = d.acc_size;  // sentinel: end of the last run
   };
   // Output chunk table (needs the parked runs: call after a barrier).  Chunk c = accumulator
-  // entries [64c, 64c+64); x = end of the run holding entry 64c, w = index of that run |
-  // slow << 16 (a third run starts inside the chunk: lanes then search).  Fixed-trip binary
-  // search: no loop in the code.
+  // entries [128c, 128c+128): x = end of the run holding entry 128c, y = delta of that run,
+  // z = delta of the next run, w = index of the first run | slow << 16 (a third run starts
+  // inside the chunk: lanes then search).  Fixed-trip binary search: no loop in the code.
   auto build_chunks = [&](const TileDesc &d, int buf) {
     if (!KMAT) return;
-    const int n_chunks = (d.acc_size + 63) >> 6;
+    const int n_chunks = (d.acc_size + kChunkLen - 1) / kChunkLen;
     if (tid < n_chunks) {
       const int *runl = runl_buf + buf * a.lds_run;
-      const int target = tid << 6;
+      const int *rund = rund_buf + buf * a.lds_run;
+      const int target = tid * kChunkLen;
       int lo = 0, hi = d.n_runs;
 #pragma unroll
       for (int it = 0; it < 10; ++it) {  // 2^10 >= kTileBlock * kRowPerLane runs
@@ -371,8 +420,10 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
         lo = up ? mid : lo;
         hi = (go && !up) ? mid : hi;
       }
-      const bool slow = lo + 2 < d.n_runs && runl[lo + 2] < target + 64;
-      ctab_buf[buf * kChunks + tid] = make_int4(runl[lo + 1], 0, 0, lo | (slow ? 1 << 16 : 0));
+      const int nxt = lo + 1 < d.n_runs ? lo + 1 : lo;
+      const bool slow = lo + 2 < d.n_runs && runl[lo + 2] < target + kChunkLen;
+      ctab_buf[buf * kChunks + tid] =
+          make_int4(runl[lo + 1], rund[lo], rund[nxt], lo | (slow ? 1 << 16 : 0));
     }
   };
 
@@ -402,6 +453,10 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
   build_chunks(dc, 0);
   __syncthreads();
 
+  if (DBG && (a.flags & 32)) {  // experiment: spread the workgroups' phases over one tile period
+    const int steps = (blockIdx.x >> 3) & 15;
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(15);  // ~1000 cycles per step
+  }
   int cur = 0;   // run / chunk-table buffer of the current tile
   int slot = 0;  // k mod 3: vertex-id buffer of the current tile
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -430,46 +485,53 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the comment above the kernel
     if (timing) t3 = stamp();
     // ---- S5 ----------------------------------------------------------------------------------
-    // wave w streams chunks w, w+8, ...: lane l owns accumulator entry 64c + l, whose run
-    // (hence its place in the CSR array) comes from the chunk table; 4 chunks in flight
+    // wave w streams chunks w, w+8, ...: lane l owns accumulator entries 128c + 2l, + 2l + 1;
+    // their run (hence their place in the CSR array) comes from the chunk table.  Both in one
+    // run: one 16-byte store, i.e. 1 KiB contiguous per wave instruction.
     if (KMAT) {
       const int4 *ctab = ctab_buf + cur * kChunks;
-      const int n_chunks = (dc.acc_size + 63) >> 6;
-      for (int c0 = wave; c0 < n_chunks; c0 += 4 * kWaves) {
-        T val[4];
-        int4 tab[4];
+      const int n_chunks = (dc.acc_size + kChunkLen - 1) / kChunkLen;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + kWaves * u < n_chunks ? c0 + kWaves * u : n_chunks - 1;
-          const int sidx = (c << 6) + lane;
-          tab[u] = ctab[c];
-          val[u] = acc[sidx < dc.acc_size ? sidx : dc.acc_size - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + kWaves * u;
-          const int sidx = (c << 6) + lane;
-          // run of this lane's entry: the chunk's first run, or the next one ...
-          int run = (tab[u].w & 0xFFFF) + (sidx < tab[u].x ? 0 : 1);
-          if (tab[u].w >> 16) {  // ... or, if more than two runs meet in this chunk (wave-
-            // uniform), one of the next 64: fixed-trip binary search
-            int lo = tab[u].w & 0xFFFF;
-            int hi = lo + 64 < dc.n_runs ? lo + 64 : dc.n_runs;
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-              const int mid = (lo + hi) >> 1;
-              const int start = runl[mid];
-              const bool up = hi - lo > 1 && start <= sidx;
-              const bool down = hi - lo > 1 && start > sidx;
-              lo = up ? mid : lo;
-              hi = down ? mid : hi;
+      for (int u = 0; u < kChunks / kWaves; ++u) {
+        const int c = wave + kWaves * u;
+        if (c < n_chunks) {  // wave-uniform
+          const int s0 = c * kChunkLen + 2 * lane;
+          const int4 tab = ctab[c];
+          const T v0 = acc[s0], v1 = acc[s0 + 1];  // entries past acc_size exist in LDS (unused)
+          if (!(tab.w >> 16)) {
+            const int d0 = s0 < tab.x ? tab.y : tab.z;
+            const int d1 = s0 + 1 < tab.x ? tab.y : tab.z;
+            if (!(DBG && (a.flags & 4))) {
+              if (d0 == d1 && s0 + 1 < dc.acc_size) {
+                buf_store2<T>(r_vals, unsigned(s0 + d0) * unsigned(sizeof(T)), v0, v1);
+              } else {  // the pair straddles two runs, or is the odd tail
+                if (s0 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + d0) * unsigned(sizeof(T)), v0);
+                if (s0 + 1 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + 1 + d1) * unsigned(sizeof(T)), v1);
+              }
             }
-            run = lo;
+          } else {  // more than two runs meet in this chunk: each entry searches the next 128
+            // runs with a fixed-trip binary search (no loop: hipcc drains vmcnt before loops)
+            int lo0 = tab.w & 0xFFFF, lo1 = lo0;
+            int hi0 = lo0 + kChunkLen < dc.n_runs ? lo0 + kChunkLen : dc.n_runs, hi1 = hi0;
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+              const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+              const int st0 = runl[m0], st1 = runl[m1];
+              const bool g0 = hi0 - lo0 > 1, g1 = hi1 - lo1 > 1;
+              lo0 = (g0 && st0 <= s0) ? m0 : lo0;
+              hi0 = (g0 && st0 > s0) ? m0 : hi0;
+              lo1 = (g1 && st1 <= s0 + 1) ? m1 : lo1;
+              hi1 = (g1 && st1 > s0 + 1) ? m1 : hi1;
+            }
+            const int e0 = rund[lo0], e1 = rund[lo1];
+            if (!(DBG && (a.flags & 4))) {
+              if (s0 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + e0) * unsigned(sizeof(T)), v0);
+              if (s0 + 1 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + 1 + e1) * unsigned(sizeof(T)), v1);
+            }
           }
-          const int delta = rund[run < dc.n_runs ? run : 0];  // always an LDS read
-          if (c < n_chunks && sidx < dc.acc_size) {
-            if (!(DBG && (a.flags & 4))) a.vals[int64_t(sidx) + delta] = val[u];
-            acc[sidx] = T(0);
+          if (s0 < dc.acc_size) {  // never clear beyond the tile's entries (+1: rounding slack)
+            acc[s0] = T(0);
+            acc[s0 + 1] = T(0);
           }
         }
       }
@@ -481,7 +543,8 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_p1_tiles_pipe(const TileArgs<
       for (int r = 0; r < kRowPerLane; ++r) {
         const int l = tid + r * kTileBlock;
         if (l < dc.n_own) {
-          if (!(DBG && (a.flags & 4))) a.fout[gid_r[l]] = facc[l];
+          if (!(DBG && (a.flags & 4)))
+            buf_store1<T>(r_fout, unsigned(gid_r[l]) * unsigned(sizeof(T)), facc[l]);
           facc[l] = T(0);
         }
       }
@@ -529,15 +592,9 @@ struct TileLaunch {
   const void *coords;
   int quad_order;
   double alpha, beta;
-  const int32_t *desc;
-  int64_t n_tiles;
-  const uint32_t *records;
-  const int32_t *vert_gid;
-  const uint16_t *row_loff;
-  const int32_t *run_delta;
-  const uint16_t *run_lstart;
-  const int32_t *elem_id;
-  int max_n_elem, max_n_vert, max_n_own, max_acc, max_n_runs;
+  const unsigned char *plan;     // packed plan, device
+  const int64_t *layout;         // host: kPlanLayoutLen entries written by tfem_tile_plan_pack
+  int64_t n_verts, n_elems, nnz;
   void *vals;       // nullptr: no matrix
   const void *fq;   // nullptr: no load vector
   void *fout;
@@ -582,31 +639,44 @@ static int launch_tiles(const TileLaunch &L) {
   TriTables tables;
   if (!build_tri_tables(L.quad_order, int(sizeof(T)), &tables))
     return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
-  if (L.n_tiles == 0) return TFEM_OK;
+  if (!L.layout || L.layout[0] == 0) return TFEM_OK;
   const bool kmat = L.vals != nullptr;
   const bool load = L.fq != nullptr;
   if (!kmat && !load) return fail(TFEM_ERR_INVALID_ARGUMENT, "nothing to assemble");
-  if (!L.coords || !L.desc || !L.records || !L.vert_gid || !L.row_loff || !L.run_delta ||
-      !L.run_lstart || (load && (!L.elem_id || !L.fout)))
+  if (!L.coords || !L.plan || !L.layout || (load && !L.fout))
     return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const int64_t *z = L.layout;  // [0..11] = plan sizes, [12..18] = byte offsets, [19] = bytes
   TileArgs<T> a;
   std::memset(&a, 0, sizeof(a));
   a.coords = static_cast<const T *>(L.coords);
-  a.desc = L.desc;
-  a.records = L.records;
-  a.vert_gid = L.vert_gid;
-  a.row_loff = L.row_loff;
-  a.run_delta = L.run_delta;
-  a.run_lstart = L.run_lstart;
-  a.elem_id = L.elem_id;
+  a.plan = L.plan;
+  a.desc = reinterpret_cast<const int32_t *>(L.plan + z[12]);
   a.fq = static_cast<const T *>(L.fq);
   a.vals = static_cast<T *>(L.vals);
   a.fout = static_cast<T *>(L.fout);
-  a.n_tiles = int(L.n_tiles);
-  a.lds_acc = (L.max_acc + 3) & ~3;
-  a.lds_vert = L.max_n_vert | 1;  // odd: lds_vert + 1 is even, every LDS array stays 8-byte aligned
-  a.lds_own = load ? ((L.max_n_own + 3) & ~3) : 0;
-  a.lds_run = (L.max_n_runs + 2) & ~1;  // even: the int4 chunk table behind it stays aligned
+  const int64_t rb = int64_t(sizeof(T));
+  const int64_t extents[5] = {L.n_verts * 2 * rb, z[19], L.n_elems * tables.nq * rb, L.nnz * rb,
+                              L.n_verts * rb};
+  for (int64_t e : extents)
+    if (e < 0 || e >= (int64_t(1) << 32))
+      return fail(TFEM_ERR_INDEX_RANGE, "an array of %lld bytes does not fit the 32-bit offsets "
+                  "of the tile kernel", (long long)e);
+  a.coords_bytes = unsigned(extents[0]);
+  a.plan_bytes = unsigned(extents[1]);
+  a.fq_bytes = load ? unsigned(extents[2]) : 0u;
+  a.vals_bytes = kmat ? unsigned(extents[3]) : 0u;
+  a.fout_bytes = load ? unsigned(extents[4]) : 0u;
+  a.off_rec = unsigned(z[13]);
+  a.off_gid = unsigned(z[14]);
+  a.off_loff = unsigned(z[15]);
+  a.off_rund = unsigned(z[16]);
+  a.off_runl = unsigned(z[17]);
+  a.off_eid = unsigned(z[18]);
+  a.n_tiles = int(z[0]);
+  a.lds_acc = (int(z[8]) + 3) & ~3;
+  a.lds_vert = int(z[6]) | 1;  // odd: lds_vert + 1 is even, every LDS array stays 8-byte aligned
+  a.lds_own = load ? ((int(z[7]) + 3) & ~3) : 0;
+  a.lds_run = (int(z[10]) + 2) & ~1;  // even: the int4 chunk table behind it stays aligned
   a.flags = L.flags < 0 ? 0 : L.flags;
   a.stamps = L.stamps;
   // W = sum_q w_q/2, M_ij = sum_q (w_q/2) l_i l_j, l_i(q) w_q/2: formed in T, quadrature order
@@ -629,9 +699,10 @@ static int launch_tiles(const TileLaunch &L) {
   lds = (lds + 15) & ~size_t(15);  // the chunk table starts 16-byte aligned
   lds += size_t(2 * kChunks) * sizeof(int4);
   if (lds > 160 * 1024) return fail(TFEM_ERR_INVALID_ARGUMENT, "tile needs %zu B of LDS", lds);
-  const int per = int((L.n_tiles + 7) / 8);
+  const int per = int((z[0] + 7) / 8);
   int per_cu = int((160 * 1024) / lds);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  const int cap = load ? 2 : 3;  // 4 resp. 6 waves per SIMD (register budget of the instantiation)
+  per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu);
   int blocks = (cu_count() * per_cu / 8) * 8;
   if (blocks > per * 8) blocks = per * 8;
   const dim3 grid{unsigned(blocks)}, block{unsigned(kTileBlock)};
@@ -676,38 +747,35 @@ int tfem_tile_capacity(int what) {
   }
 }
 
-int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int quad_order, double alpha,
-                           double beta, const int32_t *desc, int64_t n_tiles,
-                           const uint32_t *records, const int32_t *vert_gid,
-                           const uint16_t *row_loff, const int32_t *run_delta,
-                           const uint16_t *run_lstart, const int32_t *elem_id, int max_n_elem,
-                           int max_n_vert, int max_n_own, int max_acc, int max_n_runs, void *vals,
-                           const void *fq, void *fout, void *stream) {
+int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                           double alpha, double beta, const void *plan_device,
+                           const int64_t *plan_layout_host, void *vals, int64_t nnz,
+                           const void *fq, int64_t n_elems, void *fout, void *stream) {
   using namespace tfem;
   if (real_bytes != 4 && real_bytes != 8)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
-  if (int st = check_plan_limits(n_tiles, max_n_elem, max_n_vert, max_n_own, max_acc, max_n_runs))
+  if (!plan_layout_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_layout_host is NULL");
+  const int64_t *z = plan_layout_host;
+  if (int st = check_plan_limits(z[0], int(z[5]), int(z[6]), int(z[7]), int(z[8]), int(z[10])))
     return st;
-  TileLaunch L{coords, quad_order, alpha, beta, desc, n_tiles, records, vert_gid, row_loff,
-               run_delta, run_lstart, elem_id, max_n_elem, max_n_vert, max_n_own, max_acc,
-               max_n_runs, vals, fq, fout, static_cast<hipStream_t>(stream)};
+  TileLaunch L{coords, quad_order, alpha, beta, static_cast<const unsigned char *>(plan_device),
+               plan_layout_host, n_verts, n_elems, nnz, vals, fq, fout,
+               static_cast<hipStream_t>(stream)};
   return real_bytes == 8 ? launch_tiles<double>(L) : launch_tiles<float>(L);
 }
 
 // Ablation build (fp64) for tools/ablate_tiles.py.
-int tfem_p1_tiles_debug(const void *coords, int quad_order, const int32_t *desc, int64_t n_tiles,
-                        const uint32_t *records, const int32_t *vert_gid,
-                        const uint16_t *row_loff, const int32_t *run_delta,
-                        const uint16_t *run_lstart, const int32_t *elem_id, int max_n_elem,
-                        int max_n_vert, int max_n_own, int max_acc, int max_n_runs, void *vals,
-                        const void *fq, void *fout, void *stream, int flags,
-                        unsigned long long *stamps) {
+int tfem_p1_tiles_debug(const void *coords, int64_t n_verts, int quad_order,
+                        const void *plan_device, const int64_t *plan_layout_host, void *vals,
+                        int64_t nnz, const void *fq, int64_t n_elems, void *fout, void *stream,
+                        int flags, unsigned long long *stamps) {
   using namespace tfem;
-  if (int st = check_plan_limits(n_tiles, max_n_elem, max_n_vert, max_n_own, max_acc, max_n_runs))
+  const int64_t *z = plan_layout_host;
+  if (int st = check_plan_limits(z[0], int(z[5]), int(z[6]), int(z[7]), int(z[8]), int(z[10])))
     return st;
-  TileLaunch L{coords, quad_order, 1.0, 0.0, desc, n_tiles, records, vert_gid, row_loff,
-               run_delta, run_lstart, elem_id, max_n_elem, max_n_vert, max_n_own, max_acc,
-               max_n_runs, vals, fq, fout, static_cast<hipStream_t>(stream), flags & 0xFF, stamps};
+  TileLaunch L{coords, quad_order, 1.0, 0.0, static_cast<const unsigned char *>(plan_device),
+               plan_layout_host, n_verts, n_elems, nnz, vals, fq, fout,
+               static_cast<hipStream_t>(stream), flags & 0xFF, stamps};
   return launch_tiles<double>(L);
 }
 

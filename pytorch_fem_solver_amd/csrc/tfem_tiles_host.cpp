@@ -255,40 +255,50 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
   return TFEM_OK;
 }
 
-int tfem_tile_plan_sizes(const void *plan_handle, int64_t sizes[12]) {
+// Packed form: ONE blob holding desc | records | vert_gid | row_loff | run_delta | run_lstart |
+// elem_id, each 16-byte aligned, with slack behind the blob so that lanes of the last tile
+// that run past an array stay inside it.  layout[0..11] = sizes, [12..18] = byte offsets of
+// the seven arrays in that order, [19] = total bytes.
+static void plan_layout(const tfem::TilePlan &p, int64_t layout[20]) {
+  const int64_t sizes[12] = {p.n_tiles, int64_t(p.records.size() / 3), int64_t(p.vert_gid.size()),
+                             int64_t(p.row_loff.size()), int64_t(p.run_delta.size()),
+                             p.max_n_elem, p.max_n_vert, p.max_n_own, p.max_acc, p.max_row_len,
+                             p.max_n_runs, int64_t(p.run_lstart.size())};
+  for (int i = 0; i < 12; ++i) layout[i] = sizes[i];
+  const int64_t bytes[7] = {int64_t(p.desc.size()) * 4, int64_t(p.records.size()) * 4,
+                            int64_t(p.vert_gid.size()) * 4, int64_t(p.row_loff.size()) * 2,
+                            int64_t(p.run_delta.size()) * 4, int64_t(p.run_lstart.size()) * 2,
+                            int64_t(p.elem_id.size()) * 4};
+  int64_t off = 0;
+  for (int i = 0; i < 7; ++i) {
+    layout[12 + i] = off;
+    off += (bytes[i] + 15) & ~int64_t(15);
+  }
+  layout[19] = off + 64;
+}
+
+int tfem_tile_plan_sizes(const void *plan_handle, int64_t layout[20]) {
   using namespace tfem;
-  if (!plan_handle || !sizes) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
-  const auto *p = static_cast<const TilePlan *>(plan_handle);
-  sizes[0] = p->n_tiles;
-  sizes[1] = int64_t(p->records.size() / 3);
-  sizes[2] = int64_t(p->vert_gid.size());
-  sizes[3] = int64_t(p->row_loff.size());
-  sizes[4] = int64_t(p->run_delta.size());
-  sizes[5] = p->max_n_elem;
-  sizes[6] = p->max_n_vert;
-  sizes[7] = p->max_n_own;
-  sizes[8] = p->max_acc;
-  sizes[9] = p->max_row_len;
-  sizes[10] = p->max_n_runs;
-  sizes[11] = int64_t(p->run_lstart.size());
+  if (!plan_handle || !layout) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  plan_layout(*static_cast<const TilePlan *>(plan_handle), layout);
   return TFEM_OK;
 }
 
-int tfem_tile_plan_export(const void *plan_handle, int32_t *desc, uint32_t *records,
-                          int32_t *vert_gid, uint16_t *row_loff, int32_t *run_delta,
-                          uint16_t *run_lstart, int32_t *elem_id) {
+int tfem_tile_plan_pack(const void *plan_handle, void *blob_host) {
   using namespace tfem;
-  if (!plan_handle) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL plan");
+  if (!plan_handle || !blob_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   const auto *p = static_cast<const TilePlan *>(plan_handle);
-  if (desc) std::memcpy(desc, p->desc.data(), p->desc.size() * sizeof(int32_t));
-  if (records) std::memcpy(records, p->records.data(), p->records.size() * sizeof(uint32_t));
-  if (vert_gid) std::memcpy(vert_gid, p->vert_gid.data(), p->vert_gid.size() * sizeof(int32_t));
-  if (row_loff) std::memcpy(row_loff, p->row_loff.data(), p->row_loff.size() * sizeof(uint16_t));
-  if (run_delta)
-    std::memcpy(run_delta, p->run_delta.data(), p->run_delta.size() * sizeof(int32_t));
-  if (run_lstart)
-    std::memcpy(run_lstart, p->run_lstart.data(), p->run_lstart.size() * sizeof(uint16_t));
-  if (elem_id) std::memcpy(elem_id, p->elem_id.data(), p->elem_id.size() * sizeof(int32_t));
+  int64_t layout[20];
+  plan_layout(*p, layout);
+  auto *out = static_cast<unsigned char *>(blob_host);
+  std::memset(out, 0, size_t(layout[19]));
+  std::memcpy(out + layout[12], p->desc.data(), p->desc.size() * 4);
+  std::memcpy(out + layout[13], p->records.data(), p->records.size() * 4);
+  std::memcpy(out + layout[14], p->vert_gid.data(), p->vert_gid.size() * 4);
+  std::memcpy(out + layout[15], p->row_loff.data(), p->row_loff.size() * 2);
+  std::memcpy(out + layout[16], p->run_delta.data(), p->run_delta.size() * 4);
+  std::memcpy(out + layout[17], p->run_lstart.data(), p->run_lstart.size() * 2);
+  std::memcpy(out + layout[18], p->elem_id.data(), p->elem_id.size() * 4);
   return TFEM_OK;
 }
 

@@ -54,17 +54,18 @@ if p_load:
     del pts
 
 
+layout = tiles["layout"]
+
+
 def run(flags, variant):
-    _native.check(fn(_native.ptr(d["coords"]), 3, _native.ptr(tiles["desc"]), ctypes.c_int64(sz[0]),
-                     _native.ptr(tiles["records"]), _native.ptr(tiles["vert_gid"]),
-                     _native.ptr(tiles["row_loff"]), _native.ptr(tiles["run_delta"]),
-                     _native.ptr(tiles["run_lstart"]), _native.ptr(tiles["elem_id"]),
-                     sz[5], sz[6], sz[7], sz[8], sz[10], _native.ptr(vals), _native.ptr(fq),
-                     _native.ptr(fout), _native.current_stream(eng.device), flags,
-                     _native.ptr(stamps)))
+    _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
+                     _native.ptr(tiles["blob"]), ctypes.c_void_p(layout.ctypes.data),
+                     _native.ptr(vals), ctypes.c_int64(nnz), _native.ptr(fq),
+                     ctypes.c_int64(eng.n_elems), _native.ptr(fout),
+                     _native.current_stream(eng.device), flags, _native.ptr(stamps)))
 
 
-CASES = (("full", 0), ("no atomics", 1), ("no element phase", 2), ("no stores", 4),
+CASES = (("full", 0), ("full + stagger", 32), ("no atomics", 1), ("no element phase", 2), ("no stores", 4),
          ("no gather", 8), ("no atomics+no stores", 5), ("no elem+no stores", 6),
          ("no elem+no gather", 10), ("only records+zero+barriers", 14),
          ("no gather+no stores", 12))
@@ -87,7 +88,7 @@ for variant in [int(v) for v in args.variants.split(",")]:
 # in-kernel stamps (flag 16): where a wave's cycles go, per half-iteration
 names = ["S2 elem", "bar(S2)", "vmcnt0", "S3+S4", "S5 store", "bar(S5)"]
 print("cycles per tile per wave:  " + "  ".join(f"{n:>9s}" for n in names) + "      total")
-for label, extra in (("full", 0), ("no atomics", 1), ("no stores", 4), ("no gather", 8),
+for label, extra in (("full", 0), ("stagger", 32), ("no atomics", 1), ("no stores", 4), ("no gather", 8),
                      ("no atomics+stores", 5), ("no elem", 2)):
     stamps.zero_()
     run(16 | extra, 1)
