@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--grid", dest="n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
     p.add_argument("--order", type=int, default=3, help="integration order")
-    p.add_argument("--cpu-sample", type=int, default=707, help="n of the CPU-baseline sample mesh")
+    p.add_argument("--cpu-sample", type=int, default=2236, help="n of the CPU-baseline sample mesh")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | atomic | tiles")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -68,33 +68,38 @@ def measured_traffic(n, order, kernel):
 
 
 def cpu_baseline(n, order):
-    """The numpy oracle (a port of the reference's op sequence) timed on this host:
-    geometry + local K + local f + scatter into CSR values / vector."""
+    """The C/OpenMP oracle (oracle/assembly_oracle.c: a port of the reference's op sequence,
+    one element per iteration) timed on this host's cores: local K + local f + scatter into
+    CSR values / vector -- the same work as one GPU step."""
+    import __graft_entry__ as ge
+
+    ge.build_oracle()
     from oracle import assembly_oracle as orc
+    from oracle import c_oracle
     from pytorch_fem_solver_amd import meshgen
+    from pytorch_fem_solver_amd.basis.engine import symbolic_host
 
     mesh = meshgen.unit_square(n, 0.25, 0)
     verts, tris = mesh["vertices"], mesh["triangles"]
     nv = verts.shape[0]
-    rowptr, colind, slots = orc.csr_pattern(tris, nv)  # symbolic, not timed (as on the GPU)
+    _, colind, slots = symbolic_host(tris, nv)  # symbolic phase, not timed (as on the GPU)
+    fq = orc.source_sin_sin(c_oracle.points(verts, tris, order))[..., 0]
     best = float("inf")
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
-        cells = verts[tris.astype(np.int64)]
-        geo = orc.geometry(cells, 1, order)
-        k_local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
-        f_local = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
-        vals = np.bincount(slots.reshape(-1), weights=k_local.reshape(-1), minlength=colind.shape[0])
-        f = np.bincount(tris.reshape(-1), weights=f_local.reshape(-1), minlength=nv)
+        k_local, f_local = c_oracle.p1_local(verts, tris, order, 1.0, 0.0, fq)
+        vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
+        f = c_oracle.scatter_vector(f_local, tris, nv)
         best = min(best, time.perf_counter() - t0)
     del vals, f
     n_elems = tris.shape[0]
     return {
         "value": n_elems / best / 1e6,
         "unit": "Melements/s",
-        "cores": 1,
+        "cores": c_oracle.threads(),
         "kind": "port",
-        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order}, numpy oracle, best of 2",
+        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order}, C/OpenMP oracle "
+        f"(oracle/assembly_oracle.c), best of 3",
     }
 
 

@@ -403,3 +403,32 @@ def test_full_size_properties_1e6():
     local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"][sample], 3, "stiffness")
     closed = orc.p1_stiffness_closed_form(mesh_np["vertices"], mesh_np["triangles"][sample])
     assert scaled_error(local, closed) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [1000, 2236])
+def test_bench_workload_against_c_oracle_at_full_size(n):
+    """The bench's own launch (fused K + f, order 3) compared entry by entry with the
+    C/OpenMP oracle at 2e6 and at the full 9,999,392 elements."""
+    import __graft_entry__ as ge
+
+    ge.build_oracle()
+    from oracle import c_oracle
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(n, 0.25, 0)
+    verts, tris = mesh_np["vertices"], mesh_np["triangles"]
+    nv = verts.shape[0]
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+    eng = basis._engine
+    pts = c_oracle.points(verts, tris, 3)
+    fq_np = orc.source_sin_sin(pts)[..., 0]
+    vals, f = eng.assemble_system(1.0, 0.0, torch.tensor(fq_np))
+    assert eng.kernel_name() == "k_p1_tiles_pipe"
+    rowptr, colind, slots = (t.cpu().numpy() for t in eng.csr_structure())
+    k_local, f_local = c_oracle.p1_local(verts, tris, 3, 1.0, 0.0, fq_np)
+    want_vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
+    want_f = c_oracle.scatter_vector(f_local, tris, nv)
+    assert scaled_error(vals.cpu(), want_vals) <= TOL
+    assert scaled_error(f.cpu(), want_f) <= TOL
+    # the integration points the HIP geometry kernel hands to user callables
+    assert scaled_error(basis.integration_points.cpu().reshape(-1, 4, 2), pts) <= TOL

@@ -134,3 +134,33 @@ def test_fracture_geometry_and_assembly(fixture):
     n = d["out_gt_vertices_2D"].shape[0]
     k = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"]).reshape(-1, 3, 3)
     assert scaled_error(orc.assemble_dense_bilinear(k, conn, n), d["out_A"]) <= TOL
+
+
+def test_c_oracle_matches_numpy_oracle_and_golden():
+    """oracle/assembly_oracle.c (OpenMP; CPU baseline of bench.py) against the numpy oracle
+    and the reference's own outputs."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import __graft_entry__ as ge
+
+    ge.build_oracle()
+    from oracle import c_oracle
+
+    for fixture, order in (("p1_square_n8.npz", 1), ("p1_square_n8.npz", 4),
+                           ("p1_square_n5_clockwise.npz", 3), ("p1_delaunay_170.npz", 3)):
+        d = load_golden(fixture)
+        verts, tris = d["in_vertices"], d["in_triangles"]
+        n = verts.shape[0]
+        pts = c_oracle.points(verts, tris, order)
+        assert scaled_error(pts.reshape(-1, pts.shape[1], 1, 2), d[f"out_q{order}_integration_points"]) <= TOL
+        fq = orc.source_sin_sin(pts)[..., 0]
+        k, f = c_oracle.p1_local(verts, tris, order, 1.0, 1.0, fq)
+        k_np, _ = orc.p1_assemble(verts, tris, order, "stiffness_mass")
+        f_np, _ = orc.p1_assemble(verts, tris, order, "load")
+        assert scaled_error(k, k_np) <= TOL and scaled_error(f, f_np[..., 0]) <= TOL
+        rowptr, colind, slots = orc.csr_pattern(tris, n)
+        vals = c_oracle.scatter_csr(k, slots, colind.shape[0])
+        assert scaled_error(orc.csr_to_dense(rowptr, colind, vals, n), d[f"out_q{order}_K_stiffness_mass"]) <= TOL
+        fv = c_oracle.scatter_vector(f, tris, n)
+        assert scaled_error(fv.reshape(-1, 1), d[f"out_q{order}_f_load"]) <= TOL
+    assert c_oracle.threads() >= 1
