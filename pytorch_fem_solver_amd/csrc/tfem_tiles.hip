@@ -44,7 +44,10 @@ namespace tfem {
 
 // 512 lanes (8 waves) share one tile: with two workgroups per CU that is 4 waves per SIMD,
 // which is what hides the dependent fp64 / LDS latency chains of the element phase.
-constexpr int kTileBlock = 512;
+#ifndef TFEM_TILE_BLOCK
+#define TFEM_TILE_BLOCK 512
+#endif
+constexpr int kTileBlock = TFEM_TILE_BLOCK;
 constexpr int kWaves = kTileBlock / 64;
 constexpr int kElemPerLane = 2;  // tile element capacity   = 1024: two full rounds, all 8
                                  // waves equally loaded (the plan fills tiles up to it)
@@ -501,14 +504,17 @@ __global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(co
           if (!(tab.w >> 16)) {
             const int d0 = s0 < tab.x ? tab.y : tab.z;
             const int d1 = s0 + 1 < tab.x ? tab.y : tab.z;
+            unsigned long long ts0 = 0;
+            if (timing) ts0 = stamp();
             if (!(DBG && (a.flags & 4))) {
               if (d0 == d1 && s0 + 1 < dc.acc_size) {
-                buf_store2<T>(r_vals, unsigned(s0 + d0) * unsigned(sizeof(T)), v0, v1);
+                buf_store2<T>(r_vals, (unsigned(s0 + d0) * unsigned(sizeof(T))) & ((DBG && (a.flags & 64)) ? 0xFFFF0u : ~0u), v0, v1);
               } else {  // the pair straddles two runs, or is the odd tail
                 if (s0 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + d0) * unsigned(sizeof(T)), v0);
                 if (s0 + 1 < dc.acc_size) buf_store1<T>(r_vals, unsigned(s0 + 1 + d1) * unsigned(sizeof(T)), v1);
               }
             }
+            if (timing) tsum[7] += stamp() - ts0;  // cycles inside the store statements (fast chunks)
           } else {  // more than two runs meet in this chunk: each entry searches the next 128
             // runs with a fixed-trip binary search (no loop: hipcc drains vmcnt before loops)
             int lo0 = tab.w & 0xFFFF, lo1 = lo0;
@@ -701,7 +707,8 @@ static int launch_tiles(const TileLaunch &L) {
   if (lds > 160 * 1024) return fail(TFEM_ERR_INVALID_ARGUMENT, "tile needs %zu B of LDS", lds);
   const int per = int((z[0] + 7) / 8);
   int per_cu = int((160 * 1024) / lds);
-  const int cap = load ? 2 : 3;  // 4 resp. 6 waves per SIMD (register budget of the instantiation)
+  // 4 resp. 6 waves per SIMD (register budget of the instantiation)
+  const int cap = (load ? 4 : 6) * 256 / kTileBlock;
   per_cu = per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu);
   int blocks = (cu_count() * per_cu / 8) * 8;
   if (blocks > per * 8) blocks = per * 8;

@@ -65,7 +65,7 @@ def run(flags, variant):
                      _native.current_stream(eng.device), flags, _native.ptr(stamps)))
 
 
-CASES = (("full", 0), ("full + stagger", 32), ("no atomics", 1), ("no element phase", 2), ("no stores", 4),
+CASES = (("full", 0), ("full + stagger", 32), ("stores wrapped into 1 MB (L2 hits)", 64), ("no atomics", 1), ("no element phase", 2), ("no stores", 4),
          ("no gather", 8), ("no atomics+no stores", 5), ("no elem+no stores", 6),
          ("no elem+no gather", 10), ("only records+zero+barriers", 14),
          ("no gather+no stores", 12))
@@ -88,7 +88,7 @@ for variant in [int(v) for v in args.variants.split(",")]:
 # in-kernel stamps (flag 16): where a wave's cycles go, per half-iteration
 names = ["S2 elem", "bar(S2)", "vmcnt0", "S3+S4", "S5 store", "bar(S5)"]
 print("cycles per tile per wave:  " + "  ".join(f"{n:>9s}" for n in names) + "      total")
-for label, extra in (("full", 0), ("stagger", 32), ("no atomics", 1), ("no stores", 4), ("no gather", 8),
+for label, extra in (("full", 0), ("stores->1MB", 64), ("no atomics", 1), ("no stores", 4), ("no gather", 8),
                      ("no atomics+stores", 5), ("no elem", 2)):
     stamps.zero_()
     run(16 | extra, 1)
@@ -96,4 +96,5 @@ for label, extra in (("full", 0), ("stagger", 32), ("no atomics", 1), ("no store
     t = stamps.cpu().numpy().reshape(-1, 8)
     t = t[t[:, 6] > 0]
     per = t[:, :6].sum(0) / t[:, 6].sum()
-    print(f"  {label:24s} " + "  ".join(f"{x:9.0f}" for x in per) + f"  {per.sum():9.0f}")
+    print(f"  {label:24s} " + "  ".join(f"{x:9.0f}" for x in per) + f"  {per.sum():9.0f}"
+          + f"   [in store stmts: {t[:, 7].sum() / t[:, 6].sum():7.0f}]")
