@@ -432,3 +432,73 @@ def test_bench_workload_against_c_oracle_at_full_size(n):
     assert scaled_error(f.cpu(), want_f) <= TOL
     # the integration points the HIP geometry kernel hands to user callables
     assert scaled_error(basis.integration_points.cpu().reshape(-1, 4, 2), pts) <= TOL
+
+
+def test_p2_config3_properties_1e6():
+    """Config 3 (P2, 6x6 blocks, ~1e6 elements): the reference has no global P2 assembly
+    to compare with (basis.py:50-51), so check what needs no oracle -- constants lie in the
+    kernel of the stiffness operator, sum(M) = |Omega|, symmetry -- plus a strided sample of
+    local blocks against the oracle's element-level P2 (which IS pinned to the reference)."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(707, 0.25, 0)
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(polynomial_order=2, integration_order=2))
+    K = basis.integrate_bilinear_form(stiffness, layout="csr")
+    n = K.shape[0]
+    assert n == 708 * 708 + mesh_np["edges"].shape[0]
+    scale = K.values.abs().max().item()
+    assert K.matvec(torch.ones(n, 1)).abs().max().item() <= 1e-11 * scale
+    basis4 = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(polynomial_order=2, integration_order=4))
+    M = basis4.integrate_bilinear_form(mass, layout="csr")
+    assert abs(M.values.sum().item() - 1.0) <= 1e-11
+    Kc = K.to_sparse_csr().to_sparse_coo().coalesce()
+    Kt = K.to_sparse_csr().to_sparse_coo().t().coalesce()
+    assert (Kc.values() - Kt.values()).abs().max().item() <= 1e-12 * scale
+    # entries of a few elements that do not share DoFs: the assembled diagonal block of an
+    # interior edge DoF equals the sum of its two elements' local entries (oracle)
+    sample = np.arange(0, mesh_np["triangles"].shape[0], 50021)
+    cells = mesh_np["vertices"][mesh_np["triangles"][sample].astype(np.int64)]
+    geo = orc.geometry(cells, 2, 2)
+    local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+    conn6 = basis._global_dofs4elements.cpu().numpy()[sample]
+    dense_rows = K.to_sparse_csr()
+    crow, col, val = (K.crow_indices.cpu().numpy(), K.col_indices.cpu().numpy(), K.values.cpu().numpy())
+    for e in range(sample.shape[0]):
+        # vertex-vertex entries get contributions from other elements too; the entry between
+        # the element's two "own" edge DoFs of edges 0 and 1 belongs to this element alone
+        a, b = conn6[e, 3], conn6[e, 4]
+        row = slice(crow[a], crow[a + 1])
+        got = val[row][col[row] == b][0]
+        assert abs(got - local[e, 4, 3]) <= 1e-12 * scale
+
+
+def test_linear_form_is_differentiable_like_the_reference():
+    """the VPINN training step differentiates through integrate_linear_form
+    (examples/example_weak.py:132-152).  Gradient of r^T r with r = integrate_linear_form(
+    f v - v_grad @ g_theta^T) w.r.t. theta, against the same expression in plain torch."""
+    d = load_golden("p1_square_n8.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 4))
+    theta = torch.tensor([0.7, -1.3], requires_grad=True)
+
+    def field(points, th):
+        x, y = torch.split(points, 1, dim=-1)
+        return torch.cat([th[0] * torch.cos(3.0 * x) * y, th[1] * x * x - torch.sin(2.0 * y)], dim=-1)
+
+    def residual(b, th):
+        x, y = torch.split(b.integration_points, 1, dim=-1)
+        return rhs(x, y) * b.v - (b.v_grad @ field(b.integration_points, th).mT)
+
+    r = basis.integrate_linear_form(residual, theta)
+    loss = (r * r).sum()
+    (g_hip,) = torch.autograd.grad(loss, theta)
+    # plain-torch evaluation of the same reference expressions (abstract_basis.py:95-112)
+    theta2 = theta.detach().clone().requires_grad_(True)
+    integrand = (residual(basis, theta2) * basis._dx).sum(-3)
+    ref = torch.zeros(basis._basis_parameters["linear_form_shape"]).index_put(
+        (basis._global_dofs4elements.reshape(-1).long(),), integrand.reshape(-1, 1), accumulate=True
+    )
+    loss2 = (ref * ref).sum()
+    (g_ref,) = torch.autograd.grad(loss2, theta2)
+    assert scaled_error(r.detach().cpu(), ref.detach().cpu()) <= TOL
+    assert scaled_error(g_hip.cpu(), g_ref.cpu()) <= 1e-11
