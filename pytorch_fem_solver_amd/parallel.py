@@ -107,6 +107,20 @@ class InterfaceExchange:
             flat_f[self.f_idx] = buf[self.f_pos]
         return vals, f
 
+    def reduce_on(self, stream, vals=None, f=None):
+        """``reduce`` enqueued on a side stream behind the work already queued on the current
+        stream, so that the next (independent) assembly launch overlaps the exchange.  The
+        caller synchronises ``stream`` (or the device) before using vals / f."""
+        done = torch.cuda.Event()
+        done.record()  # everything queued so far on the current stream (the assembly kernel)
+        with torch.cuda.stream(stream):
+            stream.wait_event(done)
+            for t in (vals, f):
+                if t is not None:
+                    t.record_stream(stream)
+            self.reduce(vals, f)
+        return vals, f
+
     # ------------------------------------------------------------------ constructors
     @classmethod
     def from_partition(cls, mesh, element_order, bounds, rank, rowptr, colind, local_to_global,
