@@ -158,16 +158,19 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
  *   create : plan handle from connectivity, coordinates (for the curve) and the CSR
  *            pattern of tfem_csr_symbolic_*; capacities bound a tile's elements,
  *            local vertices, accumulator entries and owned rows.
- *   sizes  : fills layout[20]:
+ *   sizes  : fills layout[24]:
  *            [0] n_tiles [1] n_records [2] n_local_verts [3] n_owned_rows [4] n_runs
  *            [5] max elems/tile [6] max verts/tile [7] max owned/tile
  *            [8] max accumulator entries/tile [9] max row length [10] max runs/tile
  *            [11] n_run_starts (= n_runs + n_tiles)
  *            [12..18] byte offsets of desc, records, vert_gid, row_loff, run_delta,
- *            run_lstart, elem_id inside the packed plan; [19] bytes of the packed plan
+ *            run_lstart, elem_id inside the packed plan; [19] bytes of the packed plan;
+ *            [20] 32-bit words per element record: 3 (12-byte form) or 2 (8-byte form, used
+ *            when no row has more than 8 entries); [21..23] reserved
  *   pack   : write the packed plan (layout[19] bytes, caller-owned HOST memory):
- *            desc int32 (12 per tile) | records uint32 (3 per element record: 16 * local
- *            vertex id | 4-bit column positions << 16) | vert_gid int32 | row_loff uint16 |
+ *            desc int32 (12 per tile) | records (12-byte form: per vertex 16 * local id |
+ *            4-bit column positions << 16; 8-byte form: three 10-bit local ids, nine 3-bit
+ *            positions) | vert_gid int32 | row_loff uint16 |
  *            run_delta int32 | run_lstart uint16 | elem_id int32 (original element of every
  *            record).  An output run is a maximal group of owned rows that is contiguous in
  *            the CSR value array.  The caller copies the blob to the device once.
@@ -178,14 +181,14 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                           const int64_t *rowptr_host, const int32_t *colind_host,
                           int elem_cap, int vert_cap, int acc_cap, int own_cap,
                           void **plan_out);
-int tfem_tile_plan_sizes(const void *plan, int64_t layout[20]);
+int tfem_tile_plan_sizes(const void *plan, int64_t layout[24]);
 int tfem_tile_plan_pack(const void *plan, void *blob_host);
 void tfem_tile_plan_destroy(void *plan);
 /* Largest capacity the compiled kernel accepts: what = 0 elements, 1 local vertices,
  * 2 owned rows, 3 accumulator entries per tile. */
 int tfem_tile_capacity(int what);
 /* One launch over the tile plan (`plan_device` = DEVICE copy of the packed plan,
- * `plan_layout_host` = the HOST layout[20] of tfem_tile_plan_sizes):
+ * `plan_layout_host` = the HOST layout[24] of tfem_tile_plan_sizes):
  *   vals != NULL : CSR values of alpha * stiffness + beta * mass (every entry written
  *                  once; vals need not be initialised)        [abstract_basis.py:74-93]
  *   fq   != NULL : load vector fout[n_verts] = sum_e sum_q fq[e][q] phi_i(x_q) dx_q from
@@ -197,6 +200,43 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
                            double alpha, double beta, const void *plan_device,
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,
                            const void *fq, int64_t n_elems, void *fout, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Ring plan (HOST, once per mesh) + ring kernel (DEVICE): P1 alpha * stiffness +
+ * beta * mass in owner-computes ROW form.  Same operation as tfem_p1_assemble_tiles
+ * with vals != NULL (abstract_basis.py:74-93 fused with abstract_mesh.py:257-262,
+ * basis.py:64-96, element_tri.py:132-145), same requirements (P1, DoFs = vertices,
+ * rows of at most 16 entries), no atomics at all: one lane owns one CSR row, walks
+ * the fan of triangles around its vertex (neighbours listed in fan order as 10-bit
+ * tile-local ids, the triangle of every slot flagged with its stored orientation)
+ * and writes the row once.
+ *   create : TFEM_ERR_UNSUPPORTED when the triangles around some vertex do not form
+ *            one closed fan or open fans (an edge with three triangles, duplicated or
+ *            degenerate elements): use the tile plan for such a mesh.
+ *   sizes  : fills layout[16]: [0] n_tiles [1] n_rows [2] n_local_verts
+ *            [3] max local verts/tile [4] max owned rows/tile [5] max row length
+ *            [6] neighbour slots per row record (7 | 15) [7] dwords per row record (4 | 8)
+ *            [8..11] byte offsets of desc, rows, rowstart, vert_gid in the packed plan
+ *            [12] bytes of the packed plan [13..15] reserved
+ *   pack   : desc int32 (4 per tile: vert_off, n_vert, n_own, row_off) | row records
+ *            (bit layout: csrc/tfem_rings_host.cpp) | rowstart int32 (CSR offset of every
+ *            owned row) | vert_gid int32 (owned rows first, ascending, then the halo)
+ *   capacity: what = 0 owned rows per tile, 1 local vertices per tile
+ * ------------------------------------------------------------------------- */
+int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
+                          int64_t n_verts, const double *coords_host,
+                          const int64_t *rowptr_host, const int32_t *colind_host,
+                          int own_cap, int vert_cap, void **plan_out);
+int tfem_ring_plan_sizes(const void *plan, int64_t layout[16]);
+int tfem_ring_plan_pack(const void *plan, void *blob_host);
+void tfem_ring_plan_destroy(void *plan);
+int tfem_ring_capacity(int what);
+/* vals (nnz) = CSR values of alpha * stiffness + beta * mass; every entry of a row with
+ * at least one element is written exactly once (vals need not be initialised). */
+int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                           double alpha, double beta, const void *plan_device,
+                           const int64_t *plan_layout_host, void *vals, int64_t nnz,
+                           void *stream);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,7 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
         )
     )
     try:
-        layout = np.zeros(20, dtype=np.int64)
+        layout = np.zeros(24, dtype=np.int64)
         _native.check(lib.tfem_tile_plan_sizes(handle, c_void_p(layout.ctypes.data)))
         blob = np.zeros(int(layout[19]), dtype=np.uint8)
         _native.check(lib.tfem_tile_plan_pack(handle, c_void_p(blob.ctypes.data)))
@@ -114,7 +114,8 @@ def unpack_plan(blob, layout):
         "layout": np.ascontiguousarray(layout, dtype=np.int64),
         "sizes": np.asarray(layout[:12]),
         "desc": view(0, np.int32, 12 * z[0]),
-        "records": view(1, np.uint32, 3 * z[1]),
+        "records": view(1, np.uint32, z[20] * z[1]),
+        "rec_words": z[20],
         "vert_gid": view(2, np.int32, z[2]),
         "row_loff": view(3, np.uint16, z[3]),
         "run_delta": view(4, np.int32, z[4]),

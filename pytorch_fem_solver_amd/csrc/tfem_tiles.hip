@@ -167,12 +167,13 @@ __device__ __forceinline__ void lds_barrier() {
 
 // One element (basis.py:87-88, element_tri.py:132-145 and :41, abstract_basis.py:83/:104):
 // its 3x3 block goes to A[row v_j][col v_i] (basis.py:73-76), its 3 load entries to f[v_i].
-// Record word j = 16 * local id of vertex j | positions << 16.  `loff` maps EVERY local
+// 12-byte record: word j = 16 * local id of vertex j | positions << 16; 8-byte record
+// (REC8): word 0 = three 10-bit local ids, word 1 = nine 3-bit positions.  `loff` maps EVERY local
 // vertex to the byte offset of its row's accumulators: rows this tile does not own (halo
 // vertices) map to a small trash area that is never written out, so the element phase has
 // no branches.  Padding lanes hold a null record (a dummy vertex whose row is trash too).
 // `srcw[i]` = sum_q f_q l_i(q) w_q/2 of this element (load vector).
-template <typename T, bool KMAT, bool MASS, bool LOAD, bool DBG>
+template <typename T, bool KMAT, bool MASS, bool LOAD, bool REC8, bool DBG>
 __device__ __forceinline__ void element_to_lds(const TileArgs<T> &a, const uint32_t (&rec)[3],
                                                const T (&srcw)[3], const unsigned char *xy_bytes,
                                                const unsigned char *loff_bytes,
@@ -183,7 +184,9 @@ __device__ __forceinline__ void element_to_lds(const TileArgs<T> &a, const uint3
   uint32_t off16[3];
 #pragma unroll
   for (int v = 0; v < 3; ++v) {
-    off16[v] = rec[v] & 0xFFFFu;  // 16 * lid
+    // 16 * local id: stored as such in the 12-byte record, a 10-bit field of word 0 in the
+    // 8-byte record
+    off16[v] = REC8 ? ((rec[0] >> (10 * v)) & 0x3FFu) << 4 : rec[v] & 0xFFFFu;
     const T *p = reinterpret_cast<const T *>(xy_bytes + (sizeof(T) == 8 ? off16[v] : off16[v] >> 1));
     x[v] = p[0];
     y[v] = p[1];
@@ -213,7 +216,8 @@ __device__ __forceinline__ void element_to_lds(const TileArgs<T> &a, const uint3
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int pos = int((rec[j] >> (16 + 4 * i)) & 0xFu);
+        const int pos = REC8 ? int((rec[1] >> (3 * (3 * j + i))) & 0x7u)
+                             : int((rec[j] >> (16 + 4 * i)) & 0xFu);
         T *slot = reinterpret_cast<T *>(acc_bytes + base[j] + pos * int(sizeof(T)));
         if (DBG && (a.flags & 1)) {
           if (loc[i][j] == T(-1.2345e300)) *slot = loc[i][j];  // keeps the math alive
@@ -262,9 +266,13 @@ __device__ __forceinline__ void element_to_lds(const TileArgs<T> &a, const uint3
 // coordinate gather, 16 = in-kernel stamps.  Its results are wrong by design; the product
 // path never uses it.
 // ---------------------------------------------------------------------------------------
-template <typename T, bool KMAT, bool MASS, int QL, bool DBG>
+template <typename T, bool KMAT, bool MASS, int QL, bool REC8, bool DBG>
 __global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(const TileArgs<T> a) {
   constexpr bool LOAD = QL > 0;
+  static_assert(!REC8 || kElemPerLane == 2, "8-byte records are loaded two per lane");
+  // element slot e of this lane: 8-byte records are read two per lane (one 16-byte load),
+  // 12-byte records one per lane and round
+  auto elem_index = [&](int e) { return REC8 ? 2 * int(threadIdx.x) + e : int(threadIdx.x) + e * kTileBlock; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *acc = reinterpret_cast<T *>(smem_raw);        // [lds_acc] + trash [kTrash] + facc [lds_own]
   T *xy = acc + a.lds_acc + kTrash + a.lds_own;                          // [2 * (lds_vert + 1)]
@@ -319,18 +327,27 @@ __global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(co
 #pragma unroll
       for (int e = 0; e < kElemPerLane; ++e)
         eid[e] = int(__builtin_amdgcn_raw_buffer_load_b32(
-            r_plan, a.off_eid + unsigned(d.elem_off + tid + e * kTileBlock) * 4u, 0, 0));
+            r_plan, a.off_eid + unsigned(d.elem_off + elem_index(e)) * 4u, 0, 0));
     }
   };
   // `tile_slot` = k mod 3 of the tile being loaded: its owned vertex ids go to that LDS slot
   auto load_tile = [&](const TileDesc &d, int tile_slot) {
+    if constexpr (REC8) {
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(
+          r_plan, a.off_rec + unsigned(d.elem_off + 2 * tid) * 8u, 0, 0);
+      rec_ld[0][0] = r.x;
+      rec_ld[0][1] = r.y;
+      rec_ld[1][0] = r.z;
+      rec_ld[1][1] = r.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < kElemPerLane; ++e) {
-      const u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(
-          r_plan, a.off_rec + unsigned(d.elem_off + tid + e * kTileBlock) * 12u, 0, 0);
-      rec_ld[e][0] = r.x;
-      rec_ld[e][1] = r.y;
-      rec_ld[e][2] = r.z;
+      for (int e = 0; e < kElemPerLane; ++e) {
+        const u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(
+            r_plan, a.off_rec + unsigned(d.elem_off + tid + e * kTileBlock) * 12u, 0, 0);
+        rec_ld[e][0] = r.x;
+        rec_ld[e][1] = r.y;
+        rec_ld[e][2] = r.z;
+      }
     }
 #pragma unroll
     for (int r = 0; r < kRowPerLane; ++r) {
@@ -364,12 +381,16 @@ __global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(co
   auto take_tile = [&](const TileDesc &d, int run_buf) {
     // padding lanes get a null record: the dummy vertex three times, positions spread over
     // the trash entries
-    const uint32_t null_word = (uint32_t(a.lds_vert) << 4) | (uint32_t(lane & 15) << 16);
+    const uint32_t dv = uint32_t(a.lds_vert);
+    const uint32_t null_word[3] = {
+        REC8 ? dv | dv << 10 | dv << 20 : (dv << 4) | (uint32_t(lane & 15) << 16),
+        REC8 ? uint32_t(lane & 7) * 0x1249249u : (dv << 4) | (uint32_t(lane & 15) << 16),
+        (dv << 4) | (uint32_t(lane & 15) << 16)};
 #pragma unroll
     for (int e = 0; e < kElemPerLane; ++e) {
-      const bool real = tid + e * kTileBlock < d.n_elem;
+      const bool real = elem_index(e) < d.n_elem;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) rec[e][j] = real ? rec_ld[e][j] : null_word;
+      for (int j = 0; j < (REC8 ? 2 : 3); ++j) rec[e][j] = real ? rec_ld[e][j] : null_word[j];
       if (LOAD) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -475,8 +496,8 @@ __global__ __launch_bounds__(kTileBlock, QL > 0 ? 4 : 6) void k_p1_tiles_pipe(co
       // branch); inside the last partial wave the padding lanes process null records
 #pragma unroll
       for (int e = 0; e < kElemPerLane; ++e) {
-        if (e * kTileBlock + wave * 64 < dc.n_elem)
-          element_to_lds<T, KMAT, MASS, LOAD, DBG>(
+        if ((REC8 ? 128 * wave + e : e * kTileBlock + wave * 64) < dc.n_elem)
+          element_to_lds<T, KMAT, MASS, LOAD, REC8, DBG>(
               a, rec[e], srcw[e], reinterpret_cast<const unsigned char *>(xy),
               reinterpret_cast<const unsigned char *>(loff), reinterpret_cast<unsigned char *>(acc),
               dc.n_own, facc0, trash);
@@ -622,22 +643,31 @@ static int cu_count() {
   return cached;
 }
 
-template <typename T, bool KMAT, bool MASS, int QL>
+// The ablation build exists for fp64 stiffness (K only, and K + f at Q = 4) alone.
+template <typename T, bool KMAT, bool MASS, int QL, bool REC8>
 static void *pick_kernel(bool dbg) {
-  if (dbg) return reinterpret_cast<void *>(k_p1_tiles_pipe<T, KMAT, MASS, QL, true>);
-  return reinterpret_cast<void *>(k_p1_tiles_pipe<T, KMAT, MASS, QL, false>);
+  if constexpr (sizeof(T) == 8 && KMAT && !MASS && (QL == 0 || QL == 4)) {
+    if (dbg) return reinterpret_cast<void *>(k_p1_tiles_pipe<T, KMAT, MASS, QL, REC8, true>);
+  }
+  return reinterpret_cast<void *>(k_p1_tiles_pipe<T, KMAT, MASS, QL, REC8, false>);
 }
 
-template <typename T, bool KMAT, bool MASS>
+template <typename T, bool KMAT, bool MASS, bool REC8>
 static void *pick_q(int nq, bool load, bool dbg) {
-  if (!load) return pick_kernel<T, KMAT, MASS, 0>(dbg);
+  if (!load) return pick_kernel<T, KMAT, MASS, 0, REC8>(dbg);
   switch (nq) {
-    case 1: return pick_kernel<T, KMAT, MASS, 1>(dbg);
-    case 3: return pick_kernel<T, KMAT, MASS, 3>(dbg);
-    case 4: return pick_kernel<T, KMAT, MASS, 4>(dbg);
-    case 6: return pick_kernel<T, KMAT, MASS, 6>(dbg);
+    case 1: return pick_kernel<T, KMAT, MASS, 1, REC8>(dbg);
+    case 3: return pick_kernel<T, KMAT, MASS, 3, REC8>(dbg);
+    case 4: return pick_kernel<T, KMAT, MASS, 4, REC8>(dbg);
+    case 6: return pick_kernel<T, KMAT, MASS, 6, REC8>(dbg);
     default: return nullptr;
   }
+}
+
+template <typename T, bool REC8>
+static void *pick_form(bool kmat, bool mass, int nq, bool load, bool dbg) {
+  if (!kmat) return pick_q<T, false, false, REC8>(nq, true, dbg);
+  return mass ? pick_q<T, true, true, REC8>(nq, load, dbg) : pick_q<T, true, false, REC8>(nq, load, dbg);
 }
 
 template <typename T>
@@ -715,9 +745,12 @@ static int launch_tiles(const TileLaunch &L) {
   const dim3 grid{unsigned(blocks)}, block{unsigned(kTileBlock)};
   const bool dbg = L.flags >= 0;
   const bool mass = kmat && L.beta != 0.0;
-  void *kernel = kmat ? (mass ? pick_q<T, true, true>(tables.nq, load, dbg)
-                              : pick_q<T, true, false>(tables.nq, load, dbg))
-                      : pick_q<T, false, false>(tables.nq, true, dbg);
+  if (z[20] != 2 && z[20] != 3)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "plan layout: %lld words per record", (long long)z[20]);
+  if (z[20] == 2 && (kElemPerLane != 2 || z[6] > 1022))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "8-byte records need <= 1022 vertices per tile");
+  void *kernel = z[20] == 2 ? pick_form<T, true>(kmat, mass, tables.nq, load, dbg)
+                            : pick_form<T, false>(kmat, mass, tables.nq, load, dbg);
   if (!kernel) return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -24,7 +24,12 @@ struct TilePlan {
   // per tile (kDescStride ints): elem_off, n_elem, vert_off, n_vert, n_own, acc_size,
   // loff_off, run_off, n_runs, lrun_off, 0, 0
   std::vector<int32_t> desc;
-  std::vector<uint32_t> records;    // 3 words per tile element
+  // Element records.  12-byte form (rec_words = 3): word j = 16 * local id of vertex j |
+  // 4-bit positions << 16.  8-byte form (rec_words = 2), used when no row has more than 8
+  // entries and tiles hold at most 1022 local vertices: word 0 = three 10-bit local ids,
+  // word 1 = nine 3-bit positions (row j, column i at bit 3 * (3 j + i)).
+  int rec_words = 3;
+  std::vector<uint32_t> records;
   std::vector<int32_t> elem_id;     // original element id of every record (load vector path)
   std::vector<int32_t> vert_gid;    // global vertex id of every tile-local vertex
   std::vector<uint16_t> row_loff;   // accumulator offset of every owned row
@@ -54,6 +59,14 @@ template <typename I>
 int build(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
           const int64_t *rowptr, const int32_t *colind, int elem_cap, int vert_cap, int acc_cap,
           int own_cap, TilePlan &plan) {
+  {
+    int64_t longest = 0;
+    for (int64_t v = 0; v < n_verts; ++v) longest = std::max(longest, rowptr[v + 1] - rowptr[v]);
+    if (longest <= 8) {
+      plan.rec_words = 2;
+      vert_cap = std::min(vert_cap, 1022);
+    }
+  }
   plan.elem_cap = elem_cap;
   plan.vert_cap = vert_cap;
   plan.acc_cap = acc_cap;
@@ -180,24 +193,31 @@ int build(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
     plan.run_lstart.push_back(uint16_t(run));
     const int32_t n_runs = int32_t(plan.run_delta.size()) - run_off;
     // phase D: element records
-    const int32_t elem_off = int32_t(plan.records.size() / 3);
+    const int32_t elem_off = int32_t(plan.records.size() / size_t(plan.rec_words));
     for (int32_t e : tile_elems) {
       const I *c = conn + 3 * int64_t(e);
-      // word j: bits 0-15 = 16 * local id of vertex j (the byte offset of its coordinates
-      // in LDS), bits 16+4i.. = position of column c[i] inside row c[j] (rows owned here)
-      uint32_t word[3];
+      uint32_t pos[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // [row j][column i], owned rows only
       for (int j = 0; j < 3; ++j) {
         const int32_t row = int32_t(c[j]);
-        word[j] = uint32_t(vert_local[size_t(row)]) << 4;
         if (vert_stamp[size_t(row)] != -2 - tile) continue;  // row not owned here
         const int32_t *first = colind + rowptr[row];
         const int32_t *last = colind + rowptr[row + 1];
-        for (int i = 0; i < 3; ++i) {
-          const uint32_t pos = uint32_t(std::lower_bound(first, last, int32_t(c[i])) - first);
-          word[j] |= pos << (16 + 4 * i);
+        for (int i = 0; i < 3; ++i)
+          pos[j][i] = uint32_t(std::lower_bound(first, last, int32_t(c[i])) - first);
+      }
+      uint32_t word[3] = {0, 0, 0};
+      if (plan.rec_words == 3) {
+        for (int j = 0; j < 3; ++j) {
+          word[j] = uint32_t(vert_local[size_t(c[j])]) << 4;
+          for (int i = 0; i < 3; ++i) word[j] |= pos[j][i] << (16 + 4 * i);
+        }
+      } else {
+        for (int j = 0; j < 3; ++j) {
+          word[0] |= uint32_t(vert_local[size_t(c[j])]) << (10 * j);
+          for (int i = 0; i < 3; ++i) word[1] |= pos[j][i] << (3 * (3 * j + i));
         }
       }
-      plan.records.insert(plan.records.end(), word, word + 3);
+      plan.records.insert(plan.records.end(), word, word + plan.rec_words);
       plan.elem_id.push_back(e);
     }
     // un-own (so a later tile that references these vertices as halo numbers them afresh)
@@ -258,9 +278,10 @@ int tfem_tile_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
 // Packed form: ONE blob holding desc | records | vert_gid | row_loff | run_delta | run_lstart |
 // elem_id, each 16-byte aligned, with slack behind the blob so that lanes of the last tile
 // that run past an array stay inside it.  layout[0..11] = sizes, [12..18] = byte offsets of
-// the seven arrays in that order, [19] = total bytes.
-static void plan_layout(const tfem::TilePlan &p, int64_t layout[20]) {
-  const int64_t sizes[12] = {p.n_tiles, int64_t(p.records.size() / 3), int64_t(p.vert_gid.size()),
+// the seven arrays in that order, [19] = total bytes, [20] = words per element record.
+static void plan_layout(const tfem::TilePlan &p, int64_t layout[24]) {
+  const int64_t sizes[12] = {p.n_tiles, int64_t(p.records.size() / size_t(p.rec_words)),
+                             int64_t(p.vert_gid.size()),
                              int64_t(p.row_loff.size()), int64_t(p.run_delta.size()),
                              p.max_n_elem, p.max_n_vert, p.max_n_own, p.max_acc, p.max_row_len,
                              p.max_n_runs, int64_t(p.run_lstart.size())};
@@ -275,9 +296,11 @@ static void plan_layout(const tfem::TilePlan &p, int64_t layout[20]) {
     off += (bytes[i] + 15) & ~int64_t(15);
   }
   layout[19] = off + 64;
+  layout[20] = p.rec_words;
+  layout[21] = layout[22] = layout[23] = 0;
 }
 
-int tfem_tile_plan_sizes(const void *plan_handle, int64_t layout[20]) {
+int tfem_tile_plan_sizes(const void *plan_handle, int64_t layout[24]) {
   using namespace tfem;
   if (!plan_handle || !layout) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   plan_layout(*static_cast<const TilePlan *>(plan_handle), layout);
@@ -288,7 +311,7 @@ int tfem_tile_plan_pack(const void *plan_handle, void *blob_host) {
   using namespace tfem;
   if (!plan_handle || !blob_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   const auto *p = static_cast<const TilePlan *>(plan_handle);
-  int64_t layout[20];
+  int64_t layout[24];
   plan_layout(*p, layout);
   auto *out = static_cast<unsigned char *>(blob_host);
   std::memset(out, 0, size_t(layout[19]));

@@ -12,7 +12,8 @@ def run_plan(plan, local_blocks_by_coords, n_verts, nnz, coords):
     sizes = plan["sizes"]
     n_tiles = int(sizes[0])
     desc = plan["desc"].reshape(-1, 12)
-    rec = plan["records"].reshape(-1, 3)
+    words = int(plan.get("rec_words", 3))
+    rec = plan["records"].reshape(-1, words)
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     for t in range(n_tiles):
@@ -29,15 +30,21 @@ def run_plan(plan, local_blocks_by_coords, n_verts, nnz, coords):
         assert loff[0] == 0 and np.all(np.diff(loff) >= 0)
         acc = np.zeros(acc_size)
         r = rec[elem_off:elem_off + n_elem]
-        assert np.all((r & 0xF) == 0)
-        lid = ((r & 0xFFFF) >> 4).astype(np.int64)
+        if words == 3:
+            assert np.all((r & 0xF) == 0)
+            lid = ((r & 0xFFFF) >> 4).astype(np.int64)
+        else:
+            lid = np.stack([(r[:, 0] >> (10 * j)) & 0x3FF for j in range(3)], axis=1).astype(np.int64)
         assert lid.max(initial=0) < n_vert
         blocks = local_blocks_by_coords(xy[lid])
         for j in range(3):
             owned = lid[:, j] < n_own
             base = loff[np.where(owned, lid[:, j], 0)]
             for i in range(3):
-                pos = ((r[:, j] >> (16 + 4 * i)) & 0xF).astype(np.int64)
+                if words == 3:
+                    pos = ((r[:, j] >> (16 + 4 * i)) & 0xF).astype(np.int64)
+                else:
+                    pos = ((r[:, 1] >> (3 * (3 * j + i))) & 0x7).astype(np.int64)
                 row_len = loff[np.where(owned, lid[:, j], 0) + 1] - base
                 assert np.all(pos[owned] < row_len[owned])
                 np.add.at(acc, (base + pos)[owned], blocks[owned, i, j])
