@@ -75,6 +75,19 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
          c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "tfem_ring_plan_create": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    ),
+    "tfem_ring_plan_sizes": (c_int, [c_void_p, c_void_p]),
+    "tfem_ring_plan_pack": (c_int, [c_void_p, c_void_p]),
+    "tfem_ring_plan_destroy": (None, [c_void_p]),
+    "tfem_ring_capacity": (c_int, [c_int]),
+    "tfem_p1_assemble_rings": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
+         c_int64, c_void_p],
+    ),
     "tfem_csr_to_dense": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p],

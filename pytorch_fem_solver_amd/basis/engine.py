@@ -124,6 +124,60 @@ def unpack_plan(blob, layout):
     }
 
 
+#: ring-plan tile capacities: one owned row per lane of a 256-lane workgroup
+RING_DEFAULTS = {"own": 256, "vert": 448}
+
+
+def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap=None):
+    """Build the ring plan on the host (tfem_ring_plan_*): the row-form plan of the P1
+    stiffness/mass kernel.  Raises NotImplementedError when the triangles around a vertex
+    do not form fans (non-manifold edge, duplicated element) or a row has > 16 entries."""
+    lib = _native.load()
+    env = lambda key, default: int(os.environ.get(key, default))  # noqa: E731
+    own_cap = min(own_cap or env("TFEM_RING_OWN", RING_DEFAULTS["own"]), lib.tfem_ring_capacity(0))
+    vert_cap = min(vert_cap or env("TFEM_RING_VERT", RING_DEFAULTS["vert"]), lib.tfem_ring_capacity(1))
+    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32)).reshape(-1, 3)
+    coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
+    rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
+    colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
+    handle = c_void_p()
+    _native.check(
+        lib.tfem_ring_plan_create(
+            c_void_p(conn.ctypes.data), 4, conn.shape[0], int(n_verts),
+            c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
+            c_void_p(colind.ctypes.data), own_cap, vert_cap, ctypes.byref(handle),
+        )
+    )
+    try:
+        layout = np.zeros(16, dtype=np.int64)
+        _native.check(lib.tfem_ring_plan_sizes(handle, c_void_p(layout.ctypes.data)))
+        blob = np.zeros(int(layout[12]), dtype=np.uint8)
+        _native.check(lib.tfem_ring_plan_pack(handle, c_void_p(blob.ctypes.data)))
+    finally:
+        lib.tfem_ring_plan_destroy(handle)
+    return unpack_ring_plan(blob, layout)
+
+
+def unpack_ring_plan(blob, layout):
+    """Views of the packed ring plan's arrays (host) + the blob and layout themselves."""
+    z = [int(x) for x in layout]
+
+    def view(i, dtype, count):
+        return np.frombuffer(blob, dtype=dtype, count=count, offset=z[8 + i])
+
+    return {
+        "blob": blob,
+        "layout": np.ascontiguousarray(layout, dtype=np.int64),
+        "n_tiles": z[0],
+        "slots": z[6],
+        "words": z[7],
+        "desc": view(0, np.int32, 4 * z[0]),
+        "rows": view(1, np.uint32, z[7] * z[1]),
+        "rowstart": view(2, np.int32, z[1]),
+        "vert_gid": view(3, np.int32, z[2]),
+    }
+
+
 class AssemblyEngine:
     def __init__(self, coords, conn_geo, conn_dof, n_dofs, poly_order, quad_order, fracture=None):
         """coords (N_v,2) or (F,N_v,2); conn_geo (N_T,3) or (F,N_T,3) vertex ids (per mesh);
@@ -153,6 +207,7 @@ class AssemblyEngine:
         self._csr = None
         self._csr_host = None
         self._tiles = None
+        self._rings = None
         #: "auto" (tile plan when the mesh allows it), "tiles" or "atomic"
         self.kernel = os.environ.get("TFEM_KERNEL", "auto")
 
@@ -230,10 +285,44 @@ class AssemblyEngine:
                 raise NotImplementedError("the tile-plan kernel does not apply to this basis")
         return self._tiles or None
 
+    def _p1_plan_eligible(self):
+        return (
+            self.kernel != "atomic" and self.poly_order == 1 and self.n_fractures == 0
+            and self._host_conn_geo.dim() == 2
+            and torch.equal(self._host_conn_geo.reshape(-1).cpu().long(),
+                            self._host_conn_dof.reshape(-1).cpu().long())
+        )
+
+    def ring_plan(self):
+        """Device copy of the ring plan (row form of the P1 stiffness/mass kernel), or None
+        when this basis cannot use it (P2, fractures, fans that have no ring form)."""
+        if self._rings is None:
+            self._rings = False
+            if self.kernel in ("auto", "rings") and self._p1_plan_eligible():
+                self.csr_structure()
+                rowptr, colind = self._csr_host
+                try:
+                    plan = ring_plan_host(
+                        self._host_conn_dof.cpu().numpy(), self.n_dofs,
+                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                    )
+                except NotImplementedError:
+                    plan = None
+                if plan is not None:
+                    self._rings = {
+                        "blob": torch.from_numpy(plan["blob"]).to(self.device),
+                        "layout": plan["layout"],
+                    }
+            if self._rings is False and self.kernel == "rings":
+                raise NotImplementedError("the ring-plan kernel does not apply to this basis")
+        return self._rings or None
+
     def kernel_name(self):
-        """Name of the dominant numeric kernel as rocprofv3 reports it."""
+        """Name of the dominant numeric kernel (the one that writes K) as rocprofv3 reports it."""
         if self.poly_order != 1:
             return "k_p2_bilinear_atomic"
+        if self.ring_plan() is not None:
+            return "k_p1_rings"
         return "k_p1_tiles_pipe" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
 
     def wrap_csr(self, vals):
@@ -273,6 +362,8 @@ class AssemblyEngine:
     def bilinear(self, alpha: float, beta: float):
         """CSR values of alpha*stiffness + beta*mass (fused kernel)."""
         d = self._inputs()
+        if self.ring_plan() is not None:
+            return self._assemble_rings(alpha, beta)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
         _, colind, slots = self.csr_structure()
@@ -286,6 +377,23 @@ class AssemblyEngine:
                     float(alpha), float(beta), _native.ptr(slots), _native.ptr(vals), nnz,
                     _native.ptr(d["pinv"]), _native.ptr(d["fdet"]), self.n_fractures,
                     self.coords_per_mesh, self._stream(),
+                )
+            )
+        return vals
+
+    def _assemble_rings(self, alpha, beta):
+        """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass."""
+        d = self._inputs()
+        rings = self.ring_plan()
+        nnz = int(self.csr_structure()[1].shape[0])
+        # rows of vertices without elements are empty, every other entry is written once
+        vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self.lib.tfem_p1_assemble_rings(
+                    _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
+                    float(alpha), float(beta), _native.ptr(rings["blob"]),
+                    c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz, self._stream(),
                 )
             )
         return vals

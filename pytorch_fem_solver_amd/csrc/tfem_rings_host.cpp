@@ -1,0 +1,389 @@
+// Ring plan for the P1 stiffness/mass headline kernel (host, once per mesh).
+//
+// Owner-computes, row-centric form of the element loop (abstract_basis.py:74-93 with the
+// scatter of basis.py:64-85): the CSR rows (= vertices) are cut into spatially compact tiles
+// along a Z-order curve; one lane owns one row.  A row's record lists the row's neighbours
+// IN FAN ORDER (the order in which the incident triangles chain around the vertex) as
+// tile-local vertex ids; slot i also says whether a triangle (v, n_i, n_{i+1}) exists and
+// with which orientation it is stored in the connectivity (the reference integrates with the
+// SIGNED determinant, element_tri.py:139).  The lane evaluates every incident triangle and
+// keeps its row's entries in registers: no atomics of any kind, every CSR value written once.
+//
+// Row record, SLOTS = 7 (rows of <= 8 entries; 4 dwords) / SLOTS = 15 (<= 16 entries; 8 dwords):
+//   local id of neighbour i : 10 bits, dword i / 3, shift 10 * (i % 3)
+//   k = number of neighbours: SLOTS 7 : (w0 >> 30) | ((w1 >> 30) & 1) << 2
+//                             SLOTS 15: (w0 >> 30) | (w1 >> 30) << 2
+//   position of the diagonal inside the row
+//                           : SLOTS 7 : (w2 >> 24) & 7;  SLOTS 15: (w2 >> 30) | (w3 >> 30) << 2
+//   triangle flag of slot i (0 none, 1 = connectivity holds (v, n_i, n_next) up to rotation,
+//                            2 = it holds (v, n_next, n_i); next = i + 1, or 0 from slot k-1)
+//                           : SLOTS 7 : (w2 >> (10 + 2 i)) & 3;  SLOTS 15: (w5 >> 2 i) & 3
+//   position of column n_i inside the row
+//                           : SLOTS 7 : (w3 >> 3 i) & 7
+//                             SLOTS 15: i < 8 ? (w6 >> 4 i) & 15 : (w7 >> 4 (i - 8)) & 15
+// Supported fans: one closed cycle (interior vertex) or any number of open chains (boundary
+// vertex, several fans meeting in a vertex).  An edge with three or more triangles, a
+// duplicated or degenerate triangle, or a closed cycle beside another fan is reported as
+// TFEM_ERR_UNSUPPORTED; the caller then uses the element-record tile plan instead.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "tfem_common.hpp"
+
+namespace tfem {
+
+constexpr int kRingDescStride = 4;
+constexpr int kRingLayoutLen = 16;
+
+struct RingPlan {
+  int slots = 7, words = 4;
+  std::vector<int32_t> desc;      // per tile: vert_off, n_vert, n_own, row_off
+  std::vector<uint32_t> rows;     // `words` dwords per owned row
+  std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
+  std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
+  int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0;
+  int64_t n_tiles = 0;
+};
+
+namespace {
+
+inline uint64_t ring_spread_bits(uint64_t x) {
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+struct Fan {
+  int k = 0;
+  int32_t nb[16];   // neighbours in fan order (global ids)
+  int flag[16];     // triangle flag of every slot
+};
+
+// Fan of vertex v from its incident elements.  Returns false when the fan has no ring form.
+template <typename I>
+bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t *adj_last,
+               Fan &fan) {
+  const int nt = int(adj_last - adj_first);
+  fan.k = 0;
+  if (nt == 0) return true;
+  if (nt > 16) return false;
+  int32_t ta[16], tb[16];   // triangle t = (v, ta, tb) in connectivity order (rotated)
+  int32_t nb[17];
+  int cnt[17], tri[17][2];
+  int n_nb = 0;
+  for (int t = 0; t < nt; ++t) {
+    const I *c = conn + 3 * int64_t(adj_first[t]);
+    int j = -1, hits = 0;
+    for (int a = 0; a < 3; ++a)
+      if (int32_t(c[a]) == v) {
+        j = a;
+        ++hits;
+      }
+    if (hits != 1) return false;  // degenerate element
+    ta[t] = int32_t(c[(j + 1) % 3]);
+    tb[t] = int32_t(c[(j + 2) % 3]);
+    if (ta[t] == tb[t]) return false;
+    for (int side = 0; side < 2; ++side) {
+      const int32_t w = side ? tb[t] : ta[t];
+      int i = 0;
+      while (i < n_nb && nb[i] != w) ++i;
+      if (i == n_nb) {
+        if (n_nb == 16) return false;
+        nb[n_nb] = w;
+        cnt[n_nb] = 0;
+        ++n_nb;
+      }
+      if (cnt[i] == 2) return false;  // an edge with three triangles
+      tri[i][cnt[i]++] = t;
+    }
+  }
+  // a triangle listed twice shows up as two triangles over the same neighbour pair
+  for (int t = 0; t < nt; ++t)
+    for (int u = t + 1; u < nt; ++u)
+      if ((ta[t] == ta[u] && tb[t] == tb[u]) || (ta[t] == tb[u] && tb[t] == ta[u])) return false;
+  bool used[16] = {false};
+  bool seen[17] = {false};
+  auto index_of = [&](int32_t w) {
+    int i = 0;
+    while (nb[i] != w) ++i;
+    return i;
+  };
+  // walks from neighbour `c`; returns the neighbour index it stops at
+  auto walk = [&](int c) {
+    for (;;) {
+      seen[c] = true;
+      fan.nb[fan.k] = nb[c];
+      fan.flag[fan.k] = 0;
+      int t = -1;
+      for (int s = 0; s < cnt[c]; ++s)
+        if (!used[tri[c][s]]) {
+          t = tri[c][s];
+          break;
+        }
+      if (t < 0) {
+        ++fan.k;
+        return c;  // chain end: no triangle behind this slot
+      }
+      used[t] = true;
+      const bool forward = ta[t] == nb[c];
+      fan.flag[fan.k] = forward ? 1 : 2;
+      ++fan.k;
+      const int o = index_of(forward ? tb[t] : ta[t]);
+      if (seen[o]) return o;  // closed the cycle: slot k-1 links to the start
+      c = o;
+    }
+  };
+  bool any_end = false;
+  for (int i = 0; i < n_nb; ++i) any_end = any_end || cnt[i] == 1;
+  if (!any_end) {  // one closed cycle, started at the smallest neighbour for determinism
+    int start = 0;
+    for (int i = 1; i < n_nb; ++i)
+      if (nb[i] < nb[start]) start = i;
+    const int stop = walk(start);
+    if (stop != start || fan.k != n_nb) return false;  // several cycles
+    for (int t = 0; t < nt; ++t)
+      if (!used[t]) return false;
+    return true;
+  }
+  for (;;) {  // open chains, each started at its smaller end
+    int start = -1;
+    for (int i = 0; i < n_nb; ++i)
+      if (!seen[i] && cnt[i] == 1 && (start < 0 || nb[i] < nb[start])) start = i;
+    if (start < 0) break;
+    const int stop = walk(start);
+    if (fan.flag[fan.k - 1] != 0) return false;  // ran into a visited vertex: not a chain
+    (void)stop;
+  }
+  if (fan.k != n_nb) return false;  // a closed cycle beside the chains
+  for (int t = 0; t < nt; ++t)
+    if (!used[t]) return false;
+  return true;
+}
+
+template <typename I>
+int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
+                const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
+                RingPlan &plan) {
+  int64_t longest = 0;
+  for (int64_t v = 0; v < n_verts; ++v) longest = std::max(longest, rowptr[v + 1] - rowptr[v]);
+  if (longest > 16)
+    return fail(TFEM_ERR_UNSUPPORTED, "a row has %lld entries (> 16)", (long long)longest);
+  plan.max_row_len = int32_t(longest);
+  plan.slots = longest <= 8 ? 7 : 15;
+  plan.words = longest <= 8 ? 4 : 8;
+  // ---- Z-order of the vertices ---------------------------------------------------------
+  double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+  for (int64_t v = 0; v < n_verts; ++v)
+    for (int c = 0; c < 2; ++c) {
+      lo[c] = std::min(lo[c], coords[2 * v + c]);
+      hi[c] = std::max(hi[c], coords[2 * v + c]);
+    }
+  const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
+  std::vector<std::pair<uint64_t, int32_t>> order(static_cast<size_t>(n_verts));
+  const double scale = double(1u << 24) / span;
+  for (int64_t v = 0; v < n_verts; ++v) {
+    const uint64_t qx = std::min<uint64_t>(uint64_t((coords[2 * v] - lo[0]) * scale), (1u << 24) - 1);
+    const uint64_t qy = std::min<uint64_t>(uint64_t((coords[2 * v + 1] - lo[1]) * scale), (1u << 24) - 1);
+    order[size_t(v)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(v)};
+  }
+  std::sort(order.begin(), order.end());
+  // ---- vertex -> incident elements ------------------------------------------------------
+  std::vector<int64_t> adj_ptr(size_t(n_verts) + 1, 0);
+  for (int64_t k = 0; k < 3 * n_elems; ++k) adj_ptr[size_t(conn[k]) + 1]++;
+  std::partial_sum(adj_ptr.begin(), adj_ptr.end(), adj_ptr.begin());
+  std::vector<int32_t> adj(size_t(3 * n_elems));
+  {
+    std::vector<int64_t> cur(adj_ptr.begin(), adj_ptr.end() - 1);
+    for (int64_t e = 0; e < n_elems; ++e)
+      for (int a = 0; a < 3; ++a) adj[size_t(cur[size_t(conn[3 * e + a])]++)] = int32_t(e);
+  }
+  // ---- greedy tiling along the curve ------------------------------------------------------
+  std::vector<int32_t> vert_stamp(size_t(n_verts), -1), vert_local(size_t(n_verts), 0);
+  std::vector<int32_t> owned, fresh;
+  plan.rows.reserve(size_t(n_verts) * size_t(plan.words));
+  plan.rowstart.reserve(size_t(n_verts));
+  int64_t cursor = 0;
+  int32_t tile = 0;
+  Fan fan;
+  while (cursor < n_verts) {
+    owned.clear();
+    int n_local = 0;
+    while (cursor < n_verts && int(owned.size()) < own_cap) {
+      const int32_t u = order[size_t(cursor)].second;
+      fresh.clear();
+      if (vert_stamp[size_t(u)] != tile) fresh.push_back(u);
+      for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+        const int32_t w = colind[p];
+        if (w != u && vert_stamp[size_t(w)] != tile) fresh.push_back(w);
+      }
+      if (n_local + int(fresh.size()) > vert_cap) {
+        if (owned.empty())
+          return fail(TFEM_ERR_UNSUPPORTED, "vertex %d alone exceeds the tile capacity", u);
+        break;
+      }
+      for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
+      n_local += int(fresh.size());
+      owned.push_back(u);
+      ++cursor;
+    }
+    // local numbering: owned rows first, ascending global id (contiguous output), then the
+    // halo in order of first reference
+    std::sort(owned.begin(), owned.end());
+    const int n_own = int(owned.size());
+    const int32_t vert_off = int32_t(plan.vert_gid.size());
+    const int32_t row_off = int32_t(plan.rowstart.size());
+    for (int l = 0; l < n_own; ++l) {
+      vert_local[size_t(owned[size_t(l)])] = l;
+      vert_stamp[size_t(owned[size_t(l)])] = -2 - tile;  // numbered
+    }
+    plan.vert_gid.insert(plan.vert_gid.end(), owned.begin(), owned.end());
+    int next_local = n_own;
+    for (int l = 0; l < n_own; ++l) {
+      const int32_t u = owned[size_t(l)];
+      for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+        const int32_t w = colind[p];
+        if (vert_stamp[size_t(w)] == tile) {
+          vert_stamp[size_t(w)] = -2 - tile;
+          vert_local[size_t(w)] = next_local++;
+          plan.vert_gid.push_back(w);
+        }
+      }
+    }
+    // row records
+    for (int l = 0; l < n_own; ++l) {
+      const int32_t u = owned[size_t(l)];
+      const int len = int(rowptr[u + 1] - rowptr[u]);
+      if (!build_fan(conn, u, adj.data() + adj_ptr[size_t(u)], adj.data() + adj_ptr[size_t(u) + 1], fan))
+        return fail(TFEM_ERR_UNSUPPORTED, "the triangles around vertex %d do not form fans", u);
+      if (len != (fan.k ? fan.k + 1 : 0) || fan.k > plan.slots)
+        return fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", u, len, fan.k);
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int32_t *first = colind + rowptr[u];
+      const int32_t *last = colind + rowptr[u + 1];
+      const uint32_t k = uint32_t(fan.k);
+      const uint32_t dpos = len ? uint32_t(std::lower_bound(first, last, u) - first) : 0u;
+      for (int i = 0; i < fan.k; ++i) {
+        const uint32_t lid = uint32_t(vert_local[size_t(fan.nb[i])]);
+        const uint32_t pos = uint32_t(std::lower_bound(first, last, fan.nb[i]) - first);
+        const uint32_t flag = uint32_t(fan.flag[i]);
+        w[i / 3] |= lid << (10 * (i % 3));
+        if (plan.slots == 7) {
+          w[2] |= flag << (10 + 2 * i);
+          w[3] |= pos << (3 * i);
+        } else {
+          w[5] |= flag << (2 * i);
+          if (i < 8)
+            w[6] |= pos << (4 * i);
+          else
+            w[7] |= pos << (4 * (i - 8));
+        }
+      }
+      if (plan.slots == 7) {
+        w[0] |= (k & 3u) << 30;
+        w[1] |= (k >> 2) << 30;
+        w[2] |= dpos << 24;
+      } else {
+        w[0] |= (k & 3u) << 30;
+        w[1] |= (k >> 2) << 30;
+        w[2] |= (dpos & 3u) << 30;
+        w[3] |= (dpos >> 2) << 30;
+      }
+      plan.rows.insert(plan.rows.end(), w, w + plan.words);
+      plan.rowstart.push_back(int32_t(rowptr[u]));
+    }
+    const int32_t d[kRingDescStride] = {vert_off, next_local, n_own, row_off};
+    plan.desc.insert(plan.desc.end(), d, d + kRingDescStride);
+    plan.max_n_vert = std::max(plan.max_n_vert, next_local);
+    plan.max_n_own = std::max(plan.max_n_own, int32_t(n_own));
+    ++tile;
+  }
+  plan.n_tiles = tile;
+  return TFEM_OK;
+}
+
+void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
+  std::memset(layout, 0, sizeof(int64_t) * kRingLayoutLen);
+  layout[0] = p.n_tiles;
+  layout[1] = int64_t(p.rowstart.size());
+  layout[2] = int64_t(p.vert_gid.size());
+  layout[3] = p.max_n_vert;
+  layout[4] = p.max_n_own;
+  layout[5] = p.max_row_len;
+  layout[6] = p.slots;
+  layout[7] = p.words;
+  const int64_t bytes[4] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+                            int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4};
+  int64_t off = 0;
+  for (int i = 0; i < 4; ++i) {
+    layout[8 + i] = off;
+    off += (bytes[i] + 15) & ~int64_t(15);
+  }
+  layout[12] = off + 64;
+}
+
+}  // namespace
+}  // namespace tfem
+
+extern "C" {
+
+int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                          const double *coords_host, const int64_t *rowptr_host,
+                          const int32_t *colind_host, int own_cap, int vert_cap, void **plan_out) {
+  using namespace tfem;
+  if (!plan_out) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_out is NULL");
+  *plan_out = nullptr;
+  if (idx_bytes != 4 && idx_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "idx_bytes must be 4 or 8");
+  if (n_elems < 0 || n_verts < 0 || (n_elems > 0 && !conn_host) || (n_verts > 0 && !coords_host) ||
+      !rowptr_host || (rowptr_host[n_verts] > 0 && !colind_host))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (own_cap < 1 || vert_cap < 17 || vert_cap > 1024 || own_cap > vert_cap)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad tile capacities");
+  if (3 * n_elems >= (int64_t(1) << 31) || rowptr_host[n_verts] >= (int64_t(1) << 31))
+    return fail(TFEM_ERR_INDEX_RANGE, "mesh too large for the int32 ring plan");
+  auto *plan = new RingPlan();
+  const int st =
+      idx_bytes == 4
+          ? build_rings(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host,
+                        rowptr_host, colind_host, own_cap, vert_cap, *plan)
+          : build_rings(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host,
+                        rowptr_host, colind_host, own_cap, vert_cap, *plan);
+  if (st != TFEM_OK) {
+    delete plan;
+    return st;
+  }
+  *plan_out = plan;
+  return TFEM_OK;
+}
+
+int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[16]) {
+  using namespace tfem;
+  if (!plan_handle || !layout) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  ring_layout(*static_cast<const RingPlan *>(plan_handle), layout);
+  return TFEM_OK;
+}
+
+int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
+  using namespace tfem;
+  if (!plan_handle || !blob_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const auto *p = static_cast<const RingPlan *>(plan_handle);
+  int64_t layout[kRingLayoutLen];
+  ring_layout(*p, layout);
+  auto *out = static_cast<unsigned char *>(blob_host);
+  std::memset(out, 0, size_t(layout[12]));
+  std::memcpy(out + layout[8], p->desc.data(), p->desc.size() * 4);
+  std::memcpy(out + layout[9], p->rows.data(), p->rows.size() * 4);
+  std::memcpy(out + layout[10], p->rowstart.data(), p->rowstart.size() * 4);
+  std::memcpy(out + layout[11], p->vert_gid.data(), p->vert_gid.size() * 4);
+  return TFEM_OK;
+}
+
+void tfem_ring_plan_destroy(void *plan_handle) { delete static_cast<tfem::RingPlan *>(plan_handle); }
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""numpy walk of a ring plan exactly as k_p1_rings does it (csrc/tfem_rings.hip): decode the
+row records, evaluate the fan of every owned row from the tile-local coordinates, permute
+into CSR order, count the writes.  Test infrastructure for the host-side plan builder."""
+
+import numpy as np
+
+
+def decode_rows(rows, slots):
+    """rows (n, words) uint32 -> dict of (n, slots) arrays id / flag / pos and (n,) k / dpos."""
+    w = rows.astype(np.uint64)
+    n = w.shape[0]
+    ids = np.zeros((n, slots), dtype=np.int64)
+    flag = np.zeros((n, slots), dtype=np.int64)
+    pos = np.zeros((n, slots), dtype=np.int64)
+    for i in range(slots):
+        ids[:, i] = (w[:, i // 3] >> np.uint64(10 * (i % 3))) & np.uint64(0x3FF)
+        if slots == 7:
+            flag[:, i] = (w[:, 2] >> np.uint64(10 + 2 * i)) & np.uint64(3)
+            pos[:, i] = (w[:, 3] >> np.uint64(3 * i)) & np.uint64(7)
+        else:
+            flag[:, i] = (w[:, 5] >> np.uint64(2 * i)) & np.uint64(3)
+            pos[:, i] = (w[:, 6 + (i >> 3)] >> np.uint64(4 * (i & 7))) & np.uint64(15)
+    if slots == 7:
+        k = (w[:, 0] >> np.uint64(30)) | (((w[:, 1] >> np.uint64(30)) & np.uint64(1)) << np.uint64(2))
+        dpos = (w[:, 2] >> np.uint64(24)) & np.uint64(7)
+    else:
+        k = (w[:, 0] >> np.uint64(30)) | ((w[:, 1] >> np.uint64(30)) << np.uint64(2))
+        dpos = (w[:, 2] >> np.uint64(30)) | ((w[:, 3] >> np.uint64(30)) << np.uint64(2))
+    return {"id": ids, "flag": flag, "pos": pos, "k": k.astype(np.int64), "dpos": dpos.astype(np.int64)}
+
+
+def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0):
+    """Returns (vals, writes): CSR values of stiff_w-weighted stiffness + mass and how often
+    every CSR entry was written."""
+    slots, words = plan["slots"], plan["words"]
+    desc = plan["desc"].reshape(-1, 4)
+    rows = plan["rows"].reshape(-1, words)
+    vals = np.full(nnz, np.nan)
+    writes = np.zeros(nnz, dtype=np.int64)
+    covered = 0
+    for vert_off, n_vert, n_own, row_off in desc:
+        gid = plan["vert_gid"][vert_off:vert_off + n_vert]
+        assert n_own <= n_vert <= 1024
+        assert np.all(np.diff(gid[:n_own]) > 0), "owned rows ascending"
+        assert np.unique(gid).size == n_vert
+        xy = coords[gid]
+        rec = decode_rows(rows[row_off:row_off + n_own], slots)
+        rowstart = plan["rowstart"][row_off:row_off + n_own]
+        covered += n_own
+        for r in range(n_own):
+            k = int(rec["k"][r])
+            if k == 0:
+                continue
+            ids, flag, pos = rec["id"][r], rec["flag"][r], rec["pos"][r]
+            assert ids[:k].max() < n_vert and np.all(ids[:k] != r)
+            e = xy[ids[:k]] - xy[r]
+            off = np.zeros(k)
+            diag = 0.0
+            for i in range(k):
+                nxt = 0 if i + 1 == k else i + 1
+                if flag[i] == 0:
+                    continue
+                d = e[nxt] - e[i]
+                cross = e[i, 0] * e[nxt, 1] - e[i, 1] * e[nxt, 0]
+                sdet = cross if flag[i] == 1 else -cross
+                cs = stiff_w / sdet
+                diag += cs * d.dot(d) + mass_d * sdet
+                off[i] += -cs * d.dot(e[nxt]) + mass_o * sdet
+                off[nxt] += cs * d.dot(e[i]) + mass_o * sdet
+            targets = np.concatenate([rowstart[r] + pos[:k], [rowstart[r] + rec["dpos"][r]]])
+            assert np.unique(targets).size == k + 1
+            assert targets.max() < rowstart[r] + k + 1
+            vals[targets] = np.concatenate([off, [diag]])
+            writes[targets] += 1
+    return vals, writes, covered

@@ -314,14 +314,60 @@ def test_tile_kernel_and_atomic_kernel_agree_with_oracle(mesh_kind):
     _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
     want = orc.assemble_csr_values(local, slots, colind.shape[0])
     got = {}
-    for kernel in ("tiles", "atomic"):
+    names = {"rings": "k_p1_rings", "tiles": "k_p1_tiles_pipe", "atomic": "k_p1_bilinear_atomic"}
+    for kernel in ("rings", "tiles", "atomic"):
         basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
         basis._engine.kernel = kernel
         K = basis.integrate_bilinear_form(stiffness_mass, layout="csr")
-        assert basis._engine.kernel_name() == {"tiles": "k_p1_tiles_pipe", "atomic": "k_p1_bilinear_atomic"}[kernel]
+        assert basis._engine.kernel_name() == names[kernel]
         assert scaled_error(K.values.cpu(), want) <= TOL, kernel
         got[kernel] = K.values
     assert scaled_error(got["tiles"].cpu(), got["atomic"].cpu()) <= 1e-14
+    assert scaled_error(got["rings"].cpu(), got["atomic"].cpu()) <= 1e-13
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("form", ["stiffness", "stiffness_mass", "mass"])
+def test_ring_kernel_mixed_orientation_and_open_fans(dtype, form):
+    """The row-form kernel on a mesh whose elements are stored with mixed orientation (the
+    reference integrates with the signed determinant) and on a bow-tie mesh (two fans
+    meeting in one vertex, an isolated vertex): compared with the oracle entry by entry."""
+    from pytorch_fem_solver_amd import meshgen
+
+    torch.set_default_dtype(dtype)
+    tol = TOL if dtype == torch.float64 else 5e-6
+    mesh_np = meshgen.unit_square(90, 0.25, 4)
+    tri = mesh_np["triangles"].copy()
+    flip = np.random.default_rng(5).random(tri.shape[0]) < 0.4
+    tri[flip] = tri[flip][:, [0, 2, 1]]
+    mesh_np["triangles"] = tri
+    callable_ = {"stiffness": stiffness, "stiffness_mass": stiffness_mass, "mass": mass}[form]
+    bow = {
+        "vertices": np.array([[0, 0], [1, 0], [1, 1], [-1, 0], [-1, -1], [5, 5], [0.3, 1.2]], dtype=np.float64),
+        "triangles": np.array([[0, 1, 2], [0, 3, 4], [2, 6, 0]], dtype=np.int32),
+    }
+    for name, m in (("mixed", mesh_np), ("bow", bow)):
+        verts, tris = m["vertices"], m["triangles"]
+        nv = verts.shape[0]
+        if dtype == torch.float32:
+            verts = verts.astype(np.float32)
+        local, _ = orc.p1_assemble(verts, tris, 3, form)
+        _, colind, slots = orc.csr_pattern(tris, nv)
+        want = orc.assemble_csr_values(local, slots, colind.shape[0])
+        if name == "mixed":
+            basis = tf().Basis(tf().MeshTri(m), tf().ElementTri(1, 3))
+            basis._engine.kernel = "rings"
+            K = basis.integrate_bilinear_form(callable_, layout="csr")
+            assert basis._engine.kernel_name() == "k_p1_rings"
+            got = K.values
+        else:
+            from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
+
+            eng = AssemblyEngine(torch.tensor(verts, dtype=dtype), torch.tensor(tris), torch.tensor(tris), nv, 1, 3)
+            eng.kernel = "rings"
+            ab = {"stiffness": (1.0, 0.0), "stiffness_mass": (1.0, 1.0), "mass": (0.0, 1.0)}[form]
+            got = eng.bilinear(*ab)
+        assert scaled_error(got.cpu().double(), want) <= tol, (name, form)
 
 
 @pytest.mark.parametrize("order", [1, 2, 3, 4])
@@ -335,7 +381,7 @@ def test_fused_system_launch_matches_separate_forms(order):
     x, y = torch.split(basis.integration_points, 1, dim=-1)
     fq = rhs(x, y).reshape(-1, basis._engine.n_quad)
     vals, f = basis._engine.assemble_system(1.0, 1.0, fq)
-    assert basis._engine.kernel_name() == "k_p1_tiles_pipe"
+    assert basis._engine.kernel_name() == "k_p1_rings"
     local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "stiffness_mass")
     _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
     assert scaled_error(vals.cpu(), orc.assemble_csr_values(local, slots, colind.shape[0])) <= TOL
@@ -423,13 +469,15 @@ def test_bench_workload_against_c_oracle_at_full_size(n):
     pts = c_oracle.points(verts, tris, 3)
     fq_np = orc.source_sin_sin(pts)[..., 0]
     vals, f = eng.assemble_system(1.0, 0.0, torch.tensor(fq_np))
-    assert eng.kernel_name() == "k_p1_tiles_pipe"
+    assert eng.kernel_name() == "k_p1_rings"
     rowptr, colind, slots = (t.cpu().numpy() for t in eng.csr_structure())
     k_local, f_local = c_oracle.p1_local(verts, tris, 3, 1.0, 0.0, fq_np)
     want_vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
     want_f = c_oracle.scatter_vector(f_local, tris, nv)
     assert scaled_error(vals.cpu(), want_vals) <= TOL
     assert scaled_error(f.cpu(), want_f) <= TOL
+    # K alone (row-form kernel, the launch the roofline target is quoted on)
+    assert scaled_error(eng.bilinear(1.0, 0.0).cpu(), want_vals) <= TOL
     # the integration points the HIP geometry kernel hands to user callables
     assert scaled_error(basis.integration_points.cpu().reshape(-1, 4, 2), pts) <= TOL
 
