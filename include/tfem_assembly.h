@@ -217,8 +217,12 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *            [3] max local verts/tile [4] max owned rows/tile [5] max row length
  *            [6] neighbour slots per row record (7 | 15) [7] dwords per row record (4 | 8)
  *            [8..11] byte offsets of desc, rows, rowstart, vert_gid in the packed plan
- *            [12] bytes of the packed plan [13..15] reserved
- *   pack   : desc int32 (4 per tile: vert_off, n_vert, n_own, row_off) | row records
+ *            [12] bytes of the packed plan [13] 1 when every wave's rows are consecutive
+ *            vertices (tiles made of chunks of the numbering) [14] max halo vertices/tile
+ *            [15] reserved
+ *   pack   : desc int32 (16 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
+ *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
+ *            wave 0..3, CSR offset of the first row of wave 0..3) | row records
  *            (bit layout: csrc/tfem_rings_host.cpp) | rowstart int32 (CSR offset of every
  *            owned row) | vert_gid int32 (owned rows first, ascending, then the halo)
  *   capacity: what = 0 owned rows per tile, 1 local vertices per tile

@@ -171,7 +171,8 @@ def unpack_ring_plan(blob, layout):
         "n_tiles": z[0],
         "slots": z[6],
         "words": z[7],
-        "desc": view(0, np.int32, 4 * z[0]),
+        "chunked": bool(z[13]),
+        "desc": view(0, np.int32, 16 * z[0]),
         "rows": view(1, np.uint32, z[7] * z[1]),
         "rowstart": view(2, np.int32, z[1]),
         "vert_gid": view(3, np.int32, z[2]),

@@ -20,6 +20,8 @@
 // algorithmic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "tfem_common.hpp"
@@ -53,17 +55,27 @@ struct RingArgs {
   int lds_vert;   // vertex slots reserved in LDS
   T stiff_w;      // alpha * sum_q w_q / 2
   T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
+  int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
+                  // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 256 stamps
+  unsigned long long *stamps;  // ablation build, flag 256: 8 cycle sums per wave
 };
+
+// Ablation build only: shader-clock stamp (cdna_hip_programming.md section 7).
+__device__ __forceinline__ unsigned long long ring_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 
 typedef const int32_t __attribute__((address_space(4))) *ring_const_i32;
 
 template <typename T>
 __device__ __forceinline__ T fast_rcp(T x) {
   if constexpr (sizeof(T) == 8) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
+    // v_rcp_f64 is good to 4.6e-8 (tools/probe/rcp_accuracy.hip, measured on gfx950): one
+    // Newton step gives 2.2e-15, three orders inside the 1e-12 the parity tests assert
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
   } else {
     float r = __builtin_amdgcn_rcpf(x);
@@ -102,89 +114,203 @@ __device__ __forceinline__ void lds_xy(const T *xy, uint32_t lid, T &x, T &y) {
   y = p[1];
 }
 
-// The row of local vertex `lv`: entries of the neighbour slots in off[], the diagonal in diag.
-template <typename T, int SLOTS, bool MASS>
-__device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLOTS> &rec,
-                                         uint32_t lv, const T *xy, T (&off)[SLOTS], T &diag) {
-  const int k = rec.k();
-  T xv, yv;
-  lds_xy(xy, lv, xv, yv);
-  T px, py;
-  lds_xy(xy, rec.id(0), px, py);
-  const T e0x = px - xv, e0y = py - yv;
-  T ecx = e0x, ecy = e0y;
-  diag = T(0);
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) off[i] = T(0);
-#pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
-    const bool wrap = i + 1 == k;  // the triangle of slot k - 1 closes the fan on slot 0
-    T rx = e0x, ry = e0y;          // e of slot i + 1 as stored (slot SLOTS does not exist)
-    if (i + 1 < SLOTS) {
-      lds_xy(xy, rec.id(i + 1), px, py);
-      rx = px - xv;
-      ry = py - yv;
-    }
-    const T enx = wrap ? e0x : rx, eny = wrap ? e0y : ry;
-    const uint32_t flag = rec.flag(i);
-    const bool has = i < k && flag != 0u;
-    const T dx = enx - ecx, dy = eny - ecy;
-    const T cross = ecx * eny - ecy * enx;
-    const T sdet = flag == 1u ? cross : -cross;  // signed determinant of the stored element
-    const T cs = has ? a.stiff_w * fast_rcp<T>(sdet) : T(0);
-    const T dd = dx * dx + dy * dy;
-    const T dn = dx * enx + dy * eny;
-    const T dc = dx * ecx + dy * ecy;
-    diag = diag + cs * dd;
-    off[i] = off[i] - cs * dn;
-    T nxt = cs * dc;
-    if (MASS) {
-      const T m = has ? sdet : T(0);
-      diag = diag + a.mass_d * m;
-      off[i] = off[i] + a.mass_o * m;
-      nxt = nxt + a.mass_o * m;
-    }
-    if (i + 1 < SLOTS) off[i + 1] = off[i + 1] + (wrap ? T(0) : nxt);
-    off[0] = off[0] + (wrap ? nxt : T(0));
-    ecx = rx;
-    ecy = ry;
+// +-w or 0 by the triangle flag of a slot (1: +w, 2: -w, 0: no triangle): integer selects on
+// the bit pattern, cheaper than selects between doubles.
+template <typename T>
+__device__ __forceinline__ T flag_weight(T w, uint32_t flag) {
+  if constexpr (sizeof(T) == 8) {
+    const ru32x2 b = __builtin_bit_cast(ru32x2, w);
+    const uint32_t lo = flag ? b.x : 0u;
+    const uint32_t hi = (flag ? b.y : 0u) ^ ((flag & 2u) << 30);
+    return __builtin_bit_cast(double, ru32x2{lo, hi});
+  } else {
+    const uint32_t b = __builtin_bit_cast(uint32_t, w);
+    return __builtin_bit_cast(float, (flag ? b : 0u) ^ ((flag & 2u) << 30));
   }
 }
 
-// LDS stage pitch per row (in entries): SLOTS + 2 is odd in units of 8 bytes, which spreads
-// the 16 lanes of a ds_write_b64 group over all banks.
-template <int SLOTS>
-constexpr int ring_pitch() { return SLOTS + 2; }
-
-// Row entries -> CSR order in the wave's stage -> global memory, lanes along the CSR array.
-// `stage` = this wave's 64 * pitch entries; `rowstart`, `len` = this lane's row.
-template <typename T, int SLOTS>
-__device__ __forceinline__ void ring_flush(const RingRec<SLOTS> &rec, const T (&off)[SLOTS], T diag,
-                                           T *stage, int rowstart, int len, ring_rsrc_t r_vals) {
-  constexpr int kPitch = ring_pitch<SLOTS>();
-  constexpr int kStride = SLOTS + 1;  // entries per row slot when reading back: 8 or 16
-  const int lane = threadIdx.x & 63;
+// The row of local vertex `lv`: entries of the neighbour slots in off[0 .. k), the diagonal in
+// diag (off[k ..] is scratch).  With q_i = |e_i|^2 and p = e_i.e_next the three entries of a
+// triangle are c (p - q_next), c (p - q_i) and their negative sum, c = +-W / (e_i x e_next); the
+// mass part adds det * M.  The triangle of slot i lands in off[i] and off[i + 1]; for the slot
+// that closes the fan (i + 1 == k) the second one belongs to slot 0 and is moved there at the
+// end (slots i >= k carry flag 0 and contribute nothing).  No branches: the reciprocal chains
+// of the slots interleave.
+template <typename T, int SLOTS, bool MASS>
+__device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLOTS> &rec,
+                                         uint32_t lv, const T *xy, T (&off)[SLOTS + 1], T &diag) {
   const int k = rec.k();
-  T *mine = stage + lane * kPitch;
+  T xv, yv, px, py;
+  lds_xy(xy, lv, xv, yv);
+  const uint32_t id0 = rec.id(0);
+  lds_xy(xy, id0, px, py);
+  T ecx = px - xv, ecy = py - yv;
+  T qc = ecx * ecx + ecy * ecy;
+  T dsum = T(0);  // sum of the signed determinants around the vertex (mass part)
 #pragma unroll
-  for (int i = 0; i < SLOTS; ++i)
-    if (i < k) mine[rec.pos(i)] = off[i];
-  if (k > 0) mine[rec.dpos()] = diag;
-  __builtin_amdgcn_wave_barrier();  // same wave: LDS executes its operations in order
-  constexpr int kRowsPerStep = 64 / kStride;
-  const int sub = lane / kStride, p = lane % kStride;
+  for (int i = 0; i <= SLOTS; ++i) off[i] = T(0);
 #pragma unroll
-  for (int u = 0; u < kStride; ++u) {
-    const int r = u * kRowsPerStep + sub;  // row of this wave
-    const T v = stage[r * kPitch + p];
-    const int rs = __shfl(rowstart, r, 64);
-    const int ln = __shfl(len, r, 64);
-    if (p < ln) {
-      const unsigned byte = unsigned(rs + p) * unsigned(sizeof(T));
+  for (int i = 0; i < SLOTS; ++i) {
+    // neighbour behind slot i: slot i + 1, or slot 0 where the fan closes
+    const uint32_t idn = (i + 1 < SLOTS && i + 1 != k) ? rec.id(i + 1 < SLOTS ? i + 1 : 0) : id0;
+    lds_xy(xy, idn, px, py);
+    const T enx = px - xv, eny = py - yv;
+    const T qn = enx * enx + eny * eny;
+    const T p = ecx * enx + ecy * eny;
+    const T cross = ecx * eny - ecy * enx;  // +- the signed determinant (element_tri.py:139)
+    const uint32_t flag = rec.flag(i);      // 0 for every slot i >= k
+    const T cs = flag_weight<T>(a.stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
+    off[i] = off[i] + cs * (p - qn);
+    off[i + 1] = off[i + 1] + cs * (p - qc);
+    if (MASS) {
+      const T sdet = flag_weight<T>(T(1), flag) * cross;  // signed determinant, 0 without triangle
+      const T m = a.mass_o * sdet;
+      off[i] = off[i] + m;
+      off[i + 1] = off[i + 1] + m;
+      dsum = dsum + sdet;
+    }
+    ecx = enx;
+    ecy = eny;
+    qc = qn;
+  }
+  // the closing triangle's second entry sits in off[k]: it belongs to slot 0
+  T wrapv = off[1];
+#pragma unroll
+  for (int j = 2; j <= SLOTS; ++j) wrapv = k == j ? off[j] : wrapv;
+  // stiffness rows sum to zero (constants are in the kernel of the gradient): the diagonal is
+  // minus the sum of the off-diagonal stiffness entries; the mass part is added on top
+  T sum = off[0];
+#pragma unroll
+  for (int j = 1; j <= SLOTS; ++j) sum = sum + off[j];  // = sum_{j<k} off[j] + wrapv (once)
+  off[0] = off[0] + wrapv;
+  if (MASS) {
+    // the sum above holds stiffness AND off-diagonal mass (M_ij det, twice per triangle): take
+    // the mass out again before negating, then add the diagonal mass
+    diag = a.mass_d * dsum - (sum - T(2) * a.mass_o * dsum);
+  } else {
+    diag = -sum;
+  }
+}
+
+// Per-wave LDS stage: the wave's CSR entries, compact and in CSR order (row r of the wave
+// starts at the exclusive prefix sum of the row lengths).  Two spare entries behind the
+// 64 * (SLOTS + 1) real ones absorb the slots a row does not have, so staging has no branches.
+template <typename T, int SLOTS>
+constexpr int ring_stage_entries() { return 64 * (SLOTS + 1) + 2; }
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS): Hillis-Steele
+// inside every row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row
+// read 0), then lane 15 of rows 0 and 2 is added to rows 1 and 3 (row_bcast:15) and lane 31 to
+// rows 2 and 3 (row_bcast:31).
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// Row entries -> the wave's stage (plain LDS stores).  `pre` = stage index of this lane's row;
+// returns the number of entries the wave staged (uniform).
+template <typename T, int SLOTS>
+__device__ __forceinline__ int ring_stage(const RingRec<SLOTS> &rec, const T (&off)[SLOTS + 1], T diag,
+                                          T *stage, int &pre) {
+  const int k = rec.k();
+  const int len = k > 0 ? k + 1 : 0;
+  const int incl = wave_inclusive_scan(len);
+  pre = incl - len;
+  constexpr int kSpare = 64 * (SLOTS + 1);
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) stage[i < k ? pre + rec.pos(i) : kSpare] = off[i];
+  stage[k > 0 ? pre + rec.dpos() : kSpare] = diag;
+  return __builtin_amdgcn_readlane(incl, 63);
+}
+
+// The wave's stage -> global memory when the wave's rows form ONE run (a group of rows that is
+// contiguous in the CSR value array): stage index + delta = CSR index for the whole wave.
+// Lane j of step u takes entries 128 u + 2 j and the next one: 16-byte stores, 1 KiB
+// contiguous per wave instruction; whole steps need no per-lane test.  Every LDS read is
+// issued first (one LDS latency per tile).  Same wave as ring_stage: LDS executes a wave's
+// operations in order.
+template <typename T, int SLOTS, bool DBG = false>
+__device__ __forceinline__ void ring_store_run1(const T *stage, int total, int delta, ring_rsrc_t r_vals,
+                                                int flags = 0) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kSteps = 64 * (SLOTS + 1) / 128;
+  T va[kSteps][2];
+#pragma unroll
+  for (int u = 0; u < kSteps; ++u) {
+    va[u][0] = stage[128 * u + 2 * lane];
+    va[u][1] = stage[128 * u + 2 * lane + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < kSteps; ++u) {
+    const int s0 = 128 * u + 2 * lane;
+    const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
+    const T v0 = va[u][0], v1 = va[u][1];
+    if (DBG && (flags & 1)) {
+      if (v0 == T(-1.2345e30) && v1 == v0) __builtin_amdgcn_raw_buffer_store_b32(0u, r_vals, byte, 0, 0);
+    } else if (128 * (u + 1) <= total || s0 + 1 < total) {  // first test is wave-uniform
+      if constexpr (sizeof(T) == 8) {
+        const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
+        __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b64(
+            ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+      }
+    } else if (s0 < total) {
       if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v), r_vals, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
       else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_vals, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+    }
+  }
+}
+
+// General form: the rows of a wave form several runs (one per grid line of a Z-order tile;
+// one per row for a numbering without locality).  Per run, as above.
+template <typename T, int SLOTS, bool DBG = false>
+__device__ __forceinline__ void ring_store(const T *stage, int total, int pre, int rowstart, int len,
+                                           ring_rsrc_t r_vals, int flags = 0) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+  // lane r starts a run when its row does not continue the row of lane r - 1 (wave_shr:1)
+  const int prev_end = __builtin_amdgcn_update_dpp(-1, rowstart + len, 0x138, 0xF, 0xF, false);
+  const unsigned long long has_row = __ballot(len > 0);
+  unsigned long long starts = __ballot(len > 0 && prev_end != rowstart) | (has_row & (0ull - has_row));
+  if ((starts & (starts - 1)) == 0) {
+    const int delta = starts ? __builtin_amdgcn_readlane(rowstart, __builtin_ctzll(starts)) : 0;
+    ring_store_run1<T, SLOTS, DBG>(stage, total, delta, r_vals, flags);
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+  while (starts) {
+    const int r = __builtin_ctzll(starts);
+    starts &= starts - 1;
+    const int b = __builtin_amdgcn_readlane(pre, r);
+    const int delta = __builtin_amdgcn_readlane(rowstart, r) - b;
+    const int e = starts ? __builtin_amdgcn_readlane(pre, __builtin_ctzll(starts)) : total;
+    for (int s0 = b + 2 * lane; s0 - 2 * lane < e; s0 += 128) {
+      const T v0 = stage[s0], v1 = stage[s0 + 1];
+      const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
+      if (DBG && (flags & 1)) {
+        if (v0 == T(-1.2345e30) && v1 == v0) __builtin_amdgcn_raw_buffer_store_b32(0u, r_vals, byte, 0, 0);
+      } else if (s0 + 1 < e) {
+        if constexpr (sizeof(T) == 8) {
+          const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b64(
+              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+        }
+      } else if (s0 < e) {
+        if constexpr (sizeof(T) == 8)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -218,45 +344,223 @@ __device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, Ring
   }
 }
 
+// What one WAVE needs of a tile descriptor (16 ints, tfem_rings_host.cpp): the wave owns the
+// tile's rows [row0, row1), at most 64.  In a plan with consecutive-vertex tiles those rows
+// are the consecutive vertices gid0, gid0 + 1, ... and their CSR entries start at rs0: neither
+// the ids of the owned vertices nor the row offsets are read from memory.  Scalar loads with a
+// wave-uniform index (the plan is immutable during the launch: constant address space).
+struct RingDesc {
+  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0;
+};
+
+template <bool CHUNK>
+__device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigned off_desc, int tile,
+                                              int wave) {
+  ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 64u * unsigned(tile));
+  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0};
+  if (CHUNK) {
+    r.gid0 = d[8 + wave];
+    r.rs0 = d[12 + wave];
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------
-// One tile per workgroup.  Workgroup b works on tile (b & 7) * per + (b >> 3): consecutive
-// workgroups go to different XCDs, so every XCD (own L2) walks one contiguous piece of the
-// Z-order curve and neighbouring tiles share their halo coordinates in that L2.
+// Persistent, pipelined kernel: workgroups stay resident and walk a strided list of tiles
+// inside their XCD's piece of the curve (workgroup b: XCD b & 7, so every XCD -- own L2 --
+// walks one contiguous piece and neighbouring tiles share their halo coordinates in that L2).
+// Every lane owns one row; it also fetches the coordinates of its row's vertex and of one halo
+// vertex of the tile.  Iteration k (tile k: record and row offset in registers, coordinates in
+// xy[k & 1]):
+//   A  issue the loads of tile k+1 (row record, row offset, coordinates by the vertex ids that
+//      arrived during iteration k-1) and the vertex ids of tile k+2
+//   B  rows of tile k: LDS reads, arithmetic, entries -> the wave's stage
+//   C  s_waitcnt vmcnt(0): the loads of A were issued a whole row phase ago, the stores of
+//      tile k-1 a whole iteration ago
+//   D  coordinates of tile k+1 -> xy[(k+1) & 1]; stage -> global stores of tile k
+//   E  LDS barrier (the only one): xy[(k+1) & 1] is complete, nobody reads xy[k & 1] any more
+// Neither a load's latency nor a store's acknowledgement is waited for inside an iteration.
+// DBG = true is the ablation build of tools/time_rings.py (flags in RingArgs); its results are
+// wrong by design and the product path never uses it.
 // ---------------------------------------------------------------------------------------
-template <typename T, int SLOTS, bool MASS>
+constexpr int kRingHaloCap = kRingBlock;  // halo vertices per tile: one per lane
+
+__device__ __forceinline__ void ring_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, int SLOTS, bool MASS, bool CHUNK, bool DBG>
 __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
-  T *xy = reinterpret_cast<T *>(ring_smem);                      // [2 * lds_vert]
-  T *stage = xy + 2 * a.lds_vert;                                // [waves][64 * pitch]
+  T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
+  T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T *my_stage = stage + wave * ring_stage_entries<T, SLOTS>();
   const int per = (a.n_tiles + 7) / 8;
-  const int tile = int(blockIdx.x & 7) * per + int(blockIdx.x >> 3);
-  if (tile >= a.n_tiles || int(blockIdx.x >> 3) >= per) return;
-  ring_const_i32 d = (ring_const_i32)(uintptr_t)(a.plan + a.off_desc + 16u * unsigned(tile));
-  const int vert_off = d[0], n_vert = d[1], n_own = d[2], row_off = d[3];
+  const int xcd = blockIdx.x & 7;
+  const int j0 = blockIdx.x >> 3;
+  const int stride = gridDim.x >> 3;
+  auto tile_at = [&](int k) {
+    const int j = j0 + k * stride;
+    const int t = xcd * per + j;
+    return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
+  };
   const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
   const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
   const ring_rsrc_t r_vals = ring_rsrc(a.vals, a.vals_bytes);
+  constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
+  constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
 
-  // lanes without a row read the zero record behind the plan (k = 0: nothing is stored)
-  RingRec<SLOTS> rec;
-  const unsigned row = tid < n_own ? unsigned(row_off + tid) : 0x3FFFFFFu;
-  ring_load_rec<SLOTS>(r_plan, a.off_rows + row * unsigned(4 * RingRec<SLOTS>::kWords), rec);
-  const int rowstart = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
-  for (int l = tid; l < n_vert; l += kRingBlock) {
-    const unsigned g = __builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_gid + unsigned(vert_off + l) * 4u, 0, 0);
-    T x, y;
-    ring_load_xy<T>(r_coords, g, x, y);
-    xy[2 * l] = x;
-    xy[2 * l + 1] = y;
-  }
+  RingRec<SLOTS> rec, rec_ld;
+  int rowstart = 0, rowstart_ld = 0;
+  unsigned gid_own = 0, gid_halo = 0;        // vertex ids of the tile whose coordinates load next
+  unsigned gid_own_ld = 0, gid_halo_ld = 0;  // ... and of the tile after it
+  T own_ld[2], halo_ld[2];
+
+  // vertex ids of a tile: the lane's own row vertex and halo vertex number tid.  With
+  // consecutive-vertex tiles the own id is arithmetic on the descriptor.
+  auto load_ids = [&](const RingDesc &d, unsigned &g_own, unsigned &g_halo) {
+    const int r = d.row0 + lane;
+    if (CHUNK)
+      g_own = unsigned(d.gid0 + lane);
+    else
+      g_own = __builtin_amdgcn_raw_buffer_load_b32(
+          r_plan, a.off_gid + (r < d.row1 ? unsigned(d.vert_off + r) : kNone) * 4u, 0, 0);
+    const int h = d.n_own + tid;
+    g_halo = __builtin_amdgcn_raw_buffer_load_b32(
+        r_plan, a.off_gid + (h < d.n_vert ? unsigned(d.vert_off + h) : kNone) * 4u, 0, 0);
+  };
+  auto load_tile = [&](const RingDesc &d, unsigned g_own, unsigned g_halo) {
+    const int r = d.row0 + lane;
+    const unsigned row = r < d.row1 ? unsigned(d.row_off + r) : kNone;
+    if (!(DBG && (a.flags & 16))) {
+      ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
+      if (!CHUNK)
+        rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
+    }
+    if (!(DBG && (a.flags & 4))) {
+      ring_load_xy<T>(r_coords, g_own, own_ld[0], own_ld[1]);
+      ring_load_xy<T>(r_coords, g_halo, halo_ld[0], halo_ld[1]);
+    }
+  };
+  auto park = [&](const RingDesc &d, T *dst) {
+    const int r = d.row0 + lane;
+    if (r < d.row1) {
+      dst[2 * r] = own_ld[0];
+      dst[2 * r + 1] = own_ld[1];
+    }
+    const int h = d.n_own + tid;
+    if (h < d.n_vert) {
+      dst[2 * h] = halo_ld[0];
+      dst[2 * h + 1] = halo_ld[1];
+    }
+  };
+
+  int t_c = tile_at(0);
+  if (t_c < 0) return;  // whole workgroup, before any barrier
+  int t_n = tile_at(1), t_nn = tile_at(2);
+  RingDesc dc = ring_desc<CHUNK>(a.plan, a.off_desc, t_c, wave);
+  RingDesc dn = ring_desc<CHUNK>(a.plan, a.off_desc, t_n >= 0 ? t_n : t_c, wave);
+  RingDesc dnn = ring_desc<CHUNK>(a.plan, a.off_desc, t_nn >= 0 ? t_nn : t_c, wave);
+  // prologue: tile 0 taken over, vertex ids of tile 1 in registers
+  load_ids(dc, gid_own, gid_halo);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  load_tile(dc, gid_own, gid_halo);
+  if (t_n >= 0) load_ids(dn, gid_own_ld, gid_halo_ld);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  park(dc, xy);
+  rec = rec_ld;
+  rowstart = rowstart_ld;
+  gid_own = gid_own_ld;
+  gid_halo = gid_halo_ld;
   __syncthreads();
-  T off[SLOTS], diag;
-  ring_row<T, SLOTS, MASS>(a, rec, unsigned(tid < n_own ? tid : 0), xy, off, diag);
-  const int k = rec.k();
-  ring_flush<T, SLOTS>(rec, off, diag, stage + wave * 64 * ring_pitch<SLOTS>(), rowstart,
-                       k > 0 ? k + 1 : 0, r_vals);
+
+  int cur = 0;
+  const bool timing = DBG && (a.flags & 256);
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0;; ++k) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
+    if (timing) t0 = ring_stamp();
+    // ---- A ----
+    if (t_n >= 0) {
+      load_tile(dn, gid_own, gid_halo);
+      if (t_nn >= 0) load_ids(dnn, gid_own_ld, gid_halo_ld);
+    }
+    if (timing) t1 = ring_stamp();
+    // ---- B ----
+    T off[SLOTS + 1], diag;
+    if (!(DBG && (a.flags & 2))) {
+      const int my_row = dc.row0 + lane;
+      ring_row<T, SLOTS, MASS>(a, rec, unsigned(my_row < dc.row1 ? my_row : 0),
+                               xy + cur * 2 * a.lds_vert, off, diag);
+    } else {
+      diag = T(1);
+#pragma unroll
+      for (int i = 0; i <= SLOTS; ++i) off[i] = T(i);
+    }
+    if (timing) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t2 = ring_stamp();
+    }
+    int total = 0, pre = 0;
+    if (!(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+    const int kk = rec.k();
+    const int len_c = kk > 0 ? kk + 1 : 0;
+    if (timing) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t3 = ring_stamp();
+    }
+    // ---- C ----
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); the builtin, so that hipcc's own wait
+                                         // insertion knows the loads have landed
+    if (timing) t4 = ring_stamp();
+    // ---- D ----
+    if (t_n >= 0) park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
+    if (timing) t5 = ring_stamp();
+    if (!(DBG && (a.flags & 8))) {
+      if (CHUNK) {  // one run per wave by construction, its CSR offset in the descriptor
+        __builtin_amdgcn_wave_barrier();
+        ring_store_run1<T, SLOTS, DBG>(my_stage, total, dc.rs0, r_vals, a.flags);
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        ring_store<T, SLOTS, DBG>(my_stage, total, pre, rowstart, len_c, r_vals, a.flags);
+      }
+    }
+    if (timing) {
+      t6 = ring_stamp();
+      tsum[0] += t1 - t0;  // A load issue
+      tsum[1] += t2 - t1;  // B rows
+      tsum[2] += t3 - t2;  // stage
+      tsum[3] += t4 - t3;  // vmcnt(0)
+      tsum[4] += t5 - t4;  // park
+      tsum[5] += t6 - t5;  // stores
+      tsum[7] += 1;
+    }
+    if (t_n < 0) break;
+    rec = rec_ld;
+    rowstart = rowstart_ld;
+    gid_own = gid_own_ld;
+    gid_halo = gid_halo_ld;
+    // ---- E ----
+    ring_lds_barrier();
+    if (timing) {
+      t7 = ring_stamp();
+      tsum[6] += t7 - t6;  // barrier (and the register hand-over)
+    }
+    t_c = t_n;
+    dc = dn;
+    t_n = t_nn;
+    dn = dnn;
+    t_nn = tile_at(k + 3);
+    if (t_nn >= 0) dnn = ring_desc<CHUNK>(a.plan, a.off_desc, t_nn, wave);
+    cur ^= 1;
+  }
+  if (timing && a.stamps && lane == 0) {
+    unsigned long long *o = a.stamps + 8 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
+    for (int i = 0; i < 8; ++i) o[i] = tsum[i];
+  }
 }
 
 struct RingLaunch {
@@ -268,7 +572,35 @@ struct RingLaunch {
   int64_t n_verts, nnz;
   void *vals;
   hipStream_t stream;
+  int blocks_per_cu = 0;  // > 0: cap on resident workgroups per CU (tuning)
+  int flags = 0;          // > 0: ablation build (wrong results by design)
+  unsigned long long *stamps = nullptr;
 };
+
+static int ring_cu_count() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cached = prop.multiProcessorCount;
+    else
+      cached = 256;
+  }
+  return cached;
+}
+
+template <typename T, int SLOTS, bool MASS>
+static void *pick_ring_chunk(bool chunk) {
+  return chunk ? reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, true, false>)
+               : reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, false, false>);
+}
+
+template <typename T>
+static void *pick_ring_kernel(int slots, bool mass, bool chunk) {
+  if (slots == 7) return mass ? pick_ring_chunk<T, 7, true>(chunk) : pick_ring_chunk<T, 7, false>(chunk);
+  return mass ? pick_ring_chunk<T, 15, true>(chunk) : pick_ring_chunk<T, 15, false>(chunk);
+}
 
 template <typename T>
 static int launch_rings(const RingLaunch &L) {
@@ -278,7 +610,7 @@ static int launch_rings(const RingLaunch &L) {
   const int64_t *z = L.layout;
   if (z[0] == 0) return TFEM_OK;
   if (!L.coords || !L.plan || !L.vals) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
-  if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] ||
+  if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] || z[14] > kRingHaloCap ||
       !((z[6] == 7 && z[7] == 4) || (z[6] == 15 && z[7] == 8)) || z[5] > z[6] + 1)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "ring plan exceeds the kernel's capacities");
   RingArgs<T> a;
@@ -315,21 +647,29 @@ static int launch_rings(const RingLaunch &L) {
   a.mass_o = T(L.beta) * mo;
   const bool mass = L.beta != 0.0;
   const int slots = int(z[6]);
-  const size_t lds = size_t(2 * a.lds_vert) * sizeof(T) +
-                     size_t(kRingWaves * 64 * (slots + 2)) * sizeof(T);
-  void *kernel = nullptr;
-  if (slots == 7)
-    kernel = mass ? reinterpret_cast<void *>(k_p1_rings<T, 7, true>)
-                  : reinterpret_cast<void *>(k_p1_rings<T, 7, false>);
-  else
-    kernel = mass ? reinterpret_cast<void *>(k_p1_rings<T, 15, true>)
-                  : reinterpret_cast<void *>(k_p1_rings<T, 15, false>);
+  const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
+                     size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T);
+  const bool chunk = z[13] != 0;
+  a.flags = L.flags > 0 ? L.flags : 0;
+  a.stamps = L.stamps;
+  void *kernel = pick_ring_kernel<T>(slots, mass, chunk);
+  if constexpr (sizeof(T) == 8) {  // the ablation build exists for fp64 stiffness, 7 slots
+    if (L.flags > 0 && slots == 7 && !mass)
+      kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, true>)
+                     : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, true>);
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int per = int((z[0] + 7) / 8);
-  const dim3 grid{unsigned(per * 8)}, block{unsigned(kRingBlock)};
+  // resident workgroups: what LDS and registers allow per CU, on every CU
+  int per_cu = 0;
+  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRingBlock, lds);
+  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  if (L.blocks_per_cu > 0 && L.blocks_per_cu < per_cu) per_cu = L.blocks_per_cu;
+  const int blocks = std::min(per * 8, (ring_cu_count() * per_cu / 8) * 8);
+  const dim3 grid{unsigned(blocks)}, block{unsigned(kRingBlock)};
   void *params[] = {&a};
   hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, L.stream);
   if (e != hipSuccess) return fail(TFEM_ERR_HIP, "ring kernel launch: %s", hipGetErrorString(e));
@@ -359,7 +699,24 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
   if (!plan_layout_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_layout_host is NULL");
   RingLaunch L{coords, quad_order, alpha, beta, static_cast<const unsigned char *>(plan_device),
                plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
+  // developer switches (tools/time_rings.py)
+  if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
+  if (const char *v = std::getenv("TFEM_RINGS_DEBUG")) L.flags = std::atoi(v);
   return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
+}
+
+// Ablation build (fp64 stiffness, 7 slots) for tools/time_rings.py; `stamps` = 8 * 4 * grid
+// 64-bit words or NULL.
+int tfem_p1_rings_debug(const void *coords, int64_t n_verts, int quad_order, const void *plan_device,
+                        const int64_t *plan_layout_host, void *vals, int64_t nnz, void *stream,
+                        int flags, int blocks_per_cu, unsigned long long *stamps) {
+  using namespace tfem;
+  RingLaunch L{coords, quad_order, 1.0, 0.0, static_cast<const unsigned char *>(plan_device),
+               plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
+  L.flags = flags;
+  L.blocks_per_cu = blocks_per_cu;
+  L.stamps = stamps;
+  return launch_rings<double>(L);
 }
 
 }  // extern "C"

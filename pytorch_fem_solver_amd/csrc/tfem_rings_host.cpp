@@ -26,6 +26,8 @@
 // duplicated or degenerate triangle, or a closed cycle beside another fan is reported as
 // TFEM_ERR_UNSUPPORTED; the caller then uses the element-record tile plan instead.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -34,17 +36,22 @@
 
 namespace tfem {
 
-constexpr int kRingDescStride = 4;
+constexpr int kRingDescStride = 16;
 constexpr int kRingLayoutLen = 16;
+constexpr int kRingHaloCapHost = 256;  // halo vertices per tile: one per lane of the kernel
 
 struct RingPlan {
   int slots = 7, words = 4;
-  std::vector<int32_t> desc;      // per tile: vert_off, n_vert, n_own, row_off
+  // per tile: vert_off, n_vert, row_off, then start_0 = 0, start_1, start_2, start_3,
+  // start_4 = n_own (wave w of the workgroup owns the tile's rows [start_w, start_{w+1})),
+  // global id of the first row of wave 0..3, CSR offset of the first row of wave 0..3
+  std::vector<int32_t> desc;
   std::vector<uint32_t> rows;     // `words` dwords per owned row
   std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
   std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
-  int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0;
+  int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0, max_n_halo = 0;
   int64_t n_tiles = 0;
+  bool chunked = false;           // every wave's 64 rows are 64 consecutive vertices
 };
 
 namespace {
@@ -169,7 +176,7 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
 template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
-                RingPlan &plan) {
+                bool chunk_mode, RingPlan &plan) {
   int64_t longest = 0;
   for (int64_t v = 0; v < n_verts; ++v) longest = std::max(longest, rowptr[v + 1] - rowptr[v]);
   if (longest > 16)
@@ -203,38 +210,24 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     for (int64_t e = 0; e < n_elems; ++e)
       for (int a = 0; a < 3; ++a) adj[size_t(cur[size_t(conn[3 * e + a])]++)] = int32_t(e);
   }
-  // ---- greedy tiling along the curve ------------------------------------------------------
+  // ---- tiles -----------------------------------------------------------------------------
   std::vector<int32_t> vert_stamp(size_t(n_verts), -1), vert_local(size_t(n_verts), 0);
   std::vector<int32_t> owned, fresh;
-  plan.rows.reserve(size_t(n_verts) * size_t(plan.words));
-  plan.rowstart.reserve(size_t(n_verts));
-  int64_t cursor = 0;
+  int32_t wave_start[5] = {0, 0, 0, 0, 0};  // of the tile under construction
   int32_t tile = 0;
   Fan fan;
-  while (cursor < n_verts) {
-    owned.clear();
-    int n_local = 0;
-    while (cursor < n_verts && int(owned.size()) < own_cap) {
-      const int32_t u = order[size_t(cursor)].second;
-      fresh.clear();
-      if (vert_stamp[size_t(u)] != tile) fresh.push_back(u);
-      for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
-        const int32_t w = colind[p];
-        if (w != u && vert_stamp[size_t(w)] != tile) fresh.push_back(w);
-      }
-      if (n_local + int(fresh.size()) > vert_cap) {
-        if (owned.empty())
-          return fail(TFEM_ERR_UNSUPPORTED, "vertex %d alone exceeds the tile capacity", u);
-        break;
-      }
-      for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
-      n_local += int(fresh.size());
-      owned.push_back(u);
-      ++cursor;
+  int status = TFEM_OK;
+  // vertices `u` would add to the local set of the tile under construction
+  auto collect_fresh = [&](int32_t u) {
+    if (vert_stamp[size_t(u)] != tile) fresh.push_back(u);
+    for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+      const int32_t w = colind[p];
+      if (w != u && vert_stamp[size_t(w)] != tile) fresh.push_back(w);
     }
-    // local numbering: owned rows first, ascending global id (contiguous output), then the
-    // halo in order of first reference
-    std::sort(owned.begin(), owned.end());
+  };
+  // numbers the tile's vertices (owned rows first, in the order given, then the halo in order of
+  // first reference) and writes its row records
+  auto emit_tile = [&]() {
     const int n_own = int(owned.size());
     const int32_t vert_off = int32_t(plan.vert_gid.size());
     const int32_t row_off = int32_t(plan.rowstart.size());
@@ -255,14 +248,17 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         }
       }
     }
-    // row records
     for (int l = 0; l < n_own; ++l) {
       const int32_t u = owned[size_t(l)];
       const int len = int(rowptr[u + 1] - rowptr[u]);
-      if (!build_fan(conn, u, adj.data() + adj_ptr[size_t(u)], adj.data() + adj_ptr[size_t(u) + 1], fan))
-        return fail(TFEM_ERR_UNSUPPORTED, "the triangles around vertex %d do not form fans", u);
-      if (len != (fan.k ? fan.k + 1 : 0) || fan.k > plan.slots)
-        return fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", u, len, fan.k);
+      if (!build_fan(conn, u, adj.data() + adj_ptr[size_t(u)], adj.data() + adj_ptr[size_t(u) + 1], fan)) {
+        status = fail(TFEM_ERR_UNSUPPORTED, "the triangles around vertex %d do not form fans", u);
+        return;
+      }
+      if (len != (fan.k ? fan.k + 1 : 0) || fan.k > plan.slots) {
+        status = fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", u, len, fan.k);
+        return;
+      }
       uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       const int32_t *first = colind + rowptr[u];
       const int32_t *last = colind + rowptr[u + 1];
@@ -297,11 +293,150 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       plan.rows.insert(plan.rows.end(), w, w + plan.words);
       plan.rowstart.push_back(int32_t(rowptr[u]));
     }
-    const int32_t d[kRingDescStride] = {vert_off, next_local, n_own, row_off};
+    int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
+                                  wave_start[1], wave_start[2], wave_start[3], n_own,
+                                  0, 0, 0, 0, 0, 0, 0, 0};
+    plan.max_n_halo = std::max(plan.max_n_halo, next_local - n_own);
+    for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
+      if (wave_start[w] < wave_start[w + 1]) {
+        d[8 + w] = owned[size_t(wave_start[w])];
+        d[12 + w] = int32_t(rowptr[owned[size_t(wave_start[w])]]);
+      }
     plan.desc.insert(plan.desc.end(), d, d + kRingDescStride);
     plan.max_n_vert = std::max(plan.max_n_vert, next_local);
     plan.max_n_own = std::max(plan.max_n_own, int32_t(n_own));
     ++tile;
+  };
+  auto reset_plan = [&]() {
+    plan.desc.clear();
+    plan.rows.clear();
+    plan.rowstart.clear();
+    plan.vert_gid.clear();
+    plan.max_n_vert = plan.max_n_own = plan.max_n_halo = 0;
+    std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
+    tile = 0;
+  };
+  plan.rows.reserve(size_t(n_verts) * size_t(plan.words));
+  plan.rowstart.reserve(size_t(n_verts));
+
+  // ---- mode 1: a wave's 64 rows are 64 CONSECUTIVE vertices (one contiguous piece of the CSR
+  // array per wave: the kernel's fast output path); a tile = up to own_cap / 64 such chunks that
+  // lie next to each other (chunks sorted along the Z-order curve of their centroids).  Pays
+  // when the numbering has locality (structured generators, RCM / Morton renumbering): accepted
+  // when the tiles hold at most twice as many local vertices as the mesh has vertices.
+  const int chunks_per_tile = std::min(own_cap / 64, 4);
+  bool chunked = false;
+  if (chunk_mode && chunks_per_tile >= 1 && n_verts > 0) {
+    // chunks = up to 64 consecutive vertices; a chunk ends early where the numbering jumps
+    // (the end of a grid line): more than 32 mean vertex spacings to the next vertex
+    const double spacing = std::sqrt(std::max((hi[0] - lo[0]) * (hi[1] - lo[1]), 1e-300) / double(n_verts));
+    const double jump2 = 32.0 * 32.0 * spacing * spacing;
+    std::vector<int32_t> chunk_first;  // first vertex of every chunk, + n_verts as sentinel
+    for (int64_t seg0 = 0; seg0 < n_verts;) {
+      int64_t seg1 = seg0 + 1;  // [seg0, seg1): a piece of the numbering without a jump
+      for (; seg1 < n_verts; ++seg1) {
+        const double dx = coords[2 * seg1] - coords[2 * seg1 - 2];
+        const double dy = coords[2 * seg1 + 1] - coords[2 * seg1 - 1];
+        if (dx * dx + dy * dy > jump2) break;
+      }
+      // ceil(length / 64) chunks of equal size (+-1): every wave equally loaded
+      const int64_t len = seg1 - seg0, parts = (len + 63) / 64;
+      for (int64_t c = 0; c < parts; ++c) chunk_first.push_back(int32_t(seg0 + c * len / parts));
+      seg0 = seg1;
+    }
+    chunk_first.push_back(int32_t(n_verts));
+    const int64_t n_chunks = int64_t(chunk_first.size()) - 1;
+    std::vector<std::pair<uint64_t, int32_t>> corder(static_cast<size_t>(n_chunks));
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      const int64_t v0 = chunk_first[size_t(c)], v1 = chunk_first[size_t(c) + 1];
+      double cx = 0, cy = 0;
+      for (int64_t v = v0; v < v1; ++v) {
+        cx += coords[2 * v];
+        cy += coords[2 * v + 1];
+      }
+      cx /= double(v1 - v0);
+      cy /= double(v1 - v0);
+      const uint64_t qx = std::min<uint64_t>(uint64_t((cx - lo[0]) * scale), (1u << 24) - 1);
+      const uint64_t qy = std::min<uint64_t>(uint64_t((cy - lo[1]) * scale), (1u << 24) - 1);
+      corder[size_t(c)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(c)};
+    }
+    std::sort(corder.begin(), corder.end());
+    chunked = true;
+    std::vector<int32_t> tile_chunks, chunk_fresh;
+    int64_t ccursor = 0;
+    while (ccursor < n_chunks && chunked && status == TFEM_OK) {
+      tile_chunks.clear();
+      int n_local = 0, n_owned_rows = 0;
+      while (ccursor < n_chunks && int(tile_chunks.size()) < chunks_per_tile) {
+        const int64_t c = corder[size_t(ccursor)].second;
+        const int64_t v0 = chunk_first[size_t(c)], v1 = chunk_first[size_t(c) + 1];
+        // stamp what the chunk would add to the tile's local vertices (rolled back if the
+        // tile overflows)
+        int added = 0;
+        chunk_fresh.clear();
+        for (int64_t v = v0; v < v1; ++v) {
+          fresh.clear();
+          collect_fresh(int32_t(v));
+          for (int32_t w : fresh) {
+            vert_stamp[size_t(w)] = tile;
+            chunk_fresh.push_back(w);
+          }
+          added += int(fresh.size());
+        }
+        const int owned_after = n_owned_rows + int(v1 - v0);
+        if (n_local + added > vert_cap || n_local + added - owned_after > kRingHaloCapHost) {
+          for (int32_t w : chunk_fresh) vert_stamp[size_t(w)] = -1;  // roll back
+          if (tile_chunks.empty()) chunked = false;  // one chunk alone does not fit
+          break;
+        }
+        n_local += added;
+        n_owned_rows = owned_after;
+        tile_chunks.push_back(int32_t(c));
+        ++ccursor;
+      }
+      if (!chunked) break;
+      std::sort(tile_chunks.begin(), tile_chunks.end());
+      owned.clear();
+      for (int w = 0; w < 5; ++w) {
+        wave_start[w] = int32_t(owned.size());  // one chunk per wave
+        if (w < int(tile_chunks.size()))
+          for (int32_t v = chunk_first[size_t(tile_chunks[size_t(w)])];
+               v < chunk_first[size_t(tile_chunks[size_t(w)]) + 1]; ++v)
+            owned.push_back(v);
+      }
+      emit_tile();
+    }
+    if (status != TFEM_OK) return status;
+    if (chunked && int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
+    if (!chunked) reset_plan();
+  }
+  plan.chunked = chunked;
+
+  // ---- mode 2: greedy tiling of the VERTICES along the Z-order curve (any numbering) ------------
+  int64_t cursor = 0;
+  while (!chunked && cursor < n_verts) {
+    owned.clear();
+    int n_local = 0;
+    while (cursor < n_verts && int(owned.size()) < own_cap) {
+      const int32_t u = order[size_t(cursor)].second;
+      fresh.clear();
+      collect_fresh(u);
+      if (n_local + int(fresh.size()) > vert_cap ||
+          n_local + int(fresh.size()) - int(owned.size()) - 1 > kRingHaloCapHost) {
+        if (owned.empty())
+          return fail(TFEM_ERR_UNSUPPORTED, "vertex %d alone exceeds the tile capacity", u);
+        break;
+      }
+      for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
+      n_local += int(fresh.size());
+      owned.push_back(u);
+      ++cursor;
+    }
+    // owned rows ascending (contiguous output runs), 64 per wave
+    std::sort(owned.begin(), owned.end());
+    for (int w = 0; w < 5; ++w) wave_start[w] = std::min<int32_t>(64 * w, int32_t(owned.size()));
+    emit_tile();
+    if (status != TFEM_OK) return status;
   }
   plan.n_tiles = tile;
   return TFEM_OK;
@@ -325,6 +460,8 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
     off += (bytes[i] + 15) & ~int64_t(15);
   }
   layout[12] = off + 64;
+  layout[13] = p.chunked ? 1 : 0;
+  layout[14] = p.max_n_halo;
 }
 
 }  // namespace
@@ -343,17 +480,20 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
   if (n_elems < 0 || n_verts < 0 || (n_elems > 0 && !conn_host) || (n_verts > 0 && !coords_host) ||
       !rowptr_host || (rowptr_host[n_verts] > 0 && !colind_host))
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
-  if (own_cap < 1 || vert_cap < 17 || vert_cap > 1024 || own_cap > vert_cap)
+  if (own_cap < 1 || own_cap > 256 || vert_cap < 17 || vert_cap > 1024 || own_cap > vert_cap)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad tile capacities");
   if (3 * n_elems >= (int64_t(1) << 31) || rowptr_host[n_verts] >= (int64_t(1) << 31))
     return fail(TFEM_ERR_INDEX_RANGE, "mesh too large for the int32 ring plan");
   auto *plan = new RingPlan();
+  // developer switch: TFEM_RING_TILES=zorder disables the consecutive-vertex tiles
+  const char *mode = std::getenv("TFEM_RING_TILES");
+  const bool chunk_mode = !(mode && std::strcmp(mode, "zorder") == 0);
   const int st =
       idx_bytes == 4
           ? build_rings(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, *plan)
+                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, *plan)
           : build_rings(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, *plan);
+                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, *plan);
   if (st != TFEM_OK) {
     delete plan;
     return st;

@@ -33,19 +33,29 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0):
     """Returns (vals, writes): CSR values of stiff_w-weighted stiffness + mass and how often
     every CSR entry was written."""
     slots, words = plan["slots"], plan["words"]
-    desc = plan["desc"].reshape(-1, 4)
+    desc = plan["desc"].reshape(-1, 16)
     rows = plan["rows"].reshape(-1, words)
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
-    for vert_off, n_vert, n_own, row_off in desc:
+    for d in desc:
+        vert_off, n_vert, row_off, ws0, ws1, ws2, ws3, n_own = (int(x) for x in d[:8])
+        wave_start = [ws0, ws1, ws2, ws3, n_own]
+        assert ws0 == 0 and n_vert - n_own <= 256
+        assert all(0 <= b - a <= 64 for a, b in zip(wave_start[:-1], wave_start[1:]))
         gid = plan["vert_gid"][vert_off:vert_off + n_vert]
         assert n_own <= n_vert <= 1024
         assert np.all(np.diff(gid[:n_own]) > 0), "owned rows ascending"
+        if plan.get("chunked"):
+            for a, b in zip(wave_start[:-1], wave_start[1:]):  # a wave's rows are consecutive vertices
+                assert np.all(np.diff(gid[a:b]) == 1)
         assert np.unique(gid).size == n_vert
         xy = coords[gid]
         rec = decode_rows(rows[row_off:row_off + n_own], slots)
         rowstart = plan["rowstart"][row_off:row_off + n_own]
+        for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
+            if b > a:  # what the consecutive-vertex kernel takes from the descriptor
+                assert d[8 + w] == gid[a] and d[12 + w] == rowstart[a]
         covered += n_own
         for r in range(n_own):
             k = int(rec["k"][r])

@@ -32,6 +32,20 @@ ne = mesh_np["triangles"].shape[0]
 nv = mesh_np["vertices"].shape[0]
 ref = None
 for kernel in args.kernels.split(","):
+    os.environ.pop("TFEM_RINGS", None)
+    os.environ.pop("TFEM_RINGS_PER_CU", None)
+    os.environ.pop("TFEM_RINGS_DEBUG", None)
+    os.environ.pop("TFEM_RING_TILES", None)
+    if ":" in kernel:  # rings:simple, rings:pipe:3 (variant, workgroups per CU)
+        parts = kernel.split(":")
+        kernel = parts[0]
+        os.environ["TFEM_RINGS"] = parts[1]
+        if len(parts) > 2 and parts[2]:
+            os.environ["TFEM_RINGS_PER_CU"] = parts[2]
+        if len(parts) > 3 and parts[3]:  # ablation flags (results are wrong by design)
+            os.environ["TFEM_RINGS_DEBUG"] = parts[3]
+        if len(parts) > 4:  # zorder: vertex tiles along the Z-order curve only
+            os.environ["TFEM_RING_TILES"] = parts[4]
     basis = tf.Basis(tf.MeshTri(mesh_np), tf.ElementTri(1, 3))
     eng = basis._engine
     eng.kernel = kernel
@@ -41,23 +55,59 @@ for kernel in args.kernels.split(","):
     if kernel == "rings":
         z = eng.ring_plan()["layout"]
         print(f"ring plan: tiles {z[0]}, local verts/vertex {z[2] / nv:.3f}, max verts/tile {z[3]}, "
-              f"slots {z[6]}, plan bytes/elem {z[12] / ne:.2f}")
+              f"slots {z[6]}, plan bytes/elem {z[12] / ne:.2f}, consecutive-vertex tiles {bool(z[13])}")
     for _ in range(3):
         eng.bilinear(1.0, 0.0)
     times = []
+    batch = 10  # back-to-back launches between two events: the host's launch cost is hidden
     for _ in range(args.reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        eng.bilinear(1.0, 0.0)
+        for _ in range(batch):
+            eng.bilinear(1.0, 0.0)
         b.record()
         torch.cuda.synchronize()
-        times.append(a.elapsed_time(b) * 1e3)
+        times.append(a.elapsed_time(b) * 1e3 / batch)
     t = float(np.median(times))
     alg = 12 * ne + 16 * nv + 8 * nnz
-    print(f"{kernel:8s} {eng.kernel_name():22s} median {t:8.1f} us  min {min(times):8.1f} us  "
+    print(f"{kernel:8s} {os.environ.get('TFEM_RINGS', ''):6s} {os.environ.get('TFEM_RINGS_PER_CU', ''):2s} dbg={os.environ.get('TFEM_RINGS_DEBUG', '0'):3s} {eng.kernel_name():18s} median {t:8.1f} us  min {min(times):8.1f} us  "
           f"{ne / t:9.0f} Melem/s  algorithmic {alg / t / 1e3:7.1f} GB/s = {alg / t / 8e6 * 100:5.1f} % of 8 TB/s")
     if ref is None:
         ref = vals
     else:
         err = (vals - ref).abs().max().item() / ref.abs().max().item()
         print(f"         max scaled difference to {args.kernels.split(',')[0]}: {err:.2e}")
+
+# in-kernel stamps (ablation build, flag 256): where a wave's cycles go per tile
+import ctypes  # noqa: E402
+from pytorch_fem_solver_amd import _native  # noqa: E402
+
+if "rings" in args.kernels:
+    for key in ("TFEM_RINGS", "TFEM_RINGS_PER_CU", "TFEM_RINGS_DEBUG", "TFEM_RING_TILES"):
+        os.environ.pop(key, None)
+    basis = tf.Basis(tf.MeshTri(mesh_np), tf.ElementTri(1, 3))
+    eng = basis._engine
+    eng.kernel = "rings"
+    rings = eng.ring_plan()
+    d = eng._inputs()
+    nnz = int(eng.csr_structure()[1].shape[0])
+    vals = torch.empty(nnz)
+    stamps = torch.zeros(8 * 4 * 4096, dtype=torch.int64)
+    fn = _native.load().tfem_p1_rings_debug
+    fn.restype = ctypes.c_int
+    names = ["A loads", "B rows", "stage", "vmcnt0", "park", "stores", "barrier"]
+    print("cycles per tile per wave:   " + " ".join(f"{n:>8s}" for n in names) + "    total")
+    for label, extra in (("full", 0), ("no stores", 1), ("no arithmetic", 2), ("no gather", 4),
+                         ("no stores+arith", 3)):
+        for per_cu in (0, 2):
+            stamps.zero_()
+            _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
+                             _native.ptr(rings["blob"]), ctypes.c_void_p(rings["layout"].ctypes.data),
+                             _native.ptr(vals), ctypes.c_int64(nnz), _native.current_stream(eng.device),
+                             256 | extra, per_cu, _native.ptr(stamps)))
+            torch.cuda.synchronize()
+            t = stamps.cpu().numpy().reshape(-1, 8)
+            t = t[t[:, 7] > 0]
+            per = t[:, :7].sum(0) / t[:, 7].sum()
+            print(f"  {label:18s} wg/cu={per_cu or 'max'!s:3s} " + " ".join(f"{x:8.0f}" for x in per)
+                  + f" {per.sum():8.0f}")
