@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--order", type=int, default=3, help="integration order")
     p.add_argument("--cpu-sample", type=int, default=2236, help="n of the CPU-baseline sample mesh")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--kernel", default="auto", help="auto | atomic | tiles")
+    p.add_argument("--kernel", default="auto", help="auto | rings | tiles | atomic")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     return p.parse_args()
 
@@ -51,18 +51,26 @@ def algorithmic_bytes(n_elems, n_verts, nnz, with_load=True):
     return 12 * n_elems + 16 * n_verts + 8 * nnz + (8 * n_verts if with_load else 0)
 
 
-def measured_traffic(n, order, kernel):
+def measured_traffic(n, order, kernel, with_load):
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_bench_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction
-    of MI355X_MICROARCH.md), or None when no summary matches the workload."""
+    (profiles/r01_bench_pmc_summary.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE +
+    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), or None when no summary matches
+    the workload.  The instantiation is recognised by its name: `kernel<double, ..., Q, false>`
+    with Q = 0 for the matrix-only launch."""
     path = os.path.join(REPO, "profiles", "r01_bench_pmc_summary.json")
     try:
         with open(path) as fh:
             summary = json.load(fh)
         w = summary["workload"]
-        if (w["n"], w["order"], w["kernel"], w["mode"]) == (n, order, kernel, "K+f"):
-            return float(summary["hbm_traffic_bytes_per_launch"]["total"])
-    except (OSError, KeyError, ValueError):
+        if (w["n"], w["order"]) != (n, order):
+            return None
+        for name, entry in summary["kernels"].items():
+            if kernel + "<double" not in name:
+                continue
+            q = int(name.split(">")[0].split(",")[-2])
+            if (q > 0) == with_load:
+                return float(entry["hbm_traffic_bytes_per_launch"]["total"])
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     return None
 
@@ -232,12 +240,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, args.order, engine.kernel_name()),
+                "traffic": measured_traffic(n, args.order, engine.kernel_name(), True),
                 "algorithmic_bytes_per_launch": algo,
                 "kernel_ms": k_ms,
                 "launch": "fused K + f (52 B/element algorithmic)",
                 "stiffness_only": {
                     "kernel_ms": k_only_ms,
+                    "traffic": measured_traffic(n, args.order, engine.kernel_name(), False),
                     "algorithmic_bytes_per_launch": algorithmic_bytes(n_elems, n_verts, nnz, False),
                     "achieved": algorithmic_bytes(n_elems, n_verts, nnz, False) / (k_only_ms * 1e-3) / 1e9,
                     "frac": algorithmic_bytes(n_elems, n_verts, nnz, False) / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -219,7 +219,7 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *            [8..11] byte offsets of desc, rows, rowstart, vert_gid in the packed plan
  *            [12] bytes of the packed plan [13] 1 when every wave's rows are consecutive
  *            vertices (tiles made of chunks of the numbering) [14] max halo vertices/tile
- *            [15] reserved
+ *            [15] byte offset of row_elems in the packed plan
  *   pack   : desc int32 (16 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
  *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
  *            wave 0..3, CSR offset of the first row of wave 0..3) | row records
@@ -236,11 +236,15 @@ int tfem_ring_plan_pack(const void *plan, void *blob_host);
 void tfem_ring_plan_destroy(void *plan);
 int tfem_ring_capacity(int what);
 /* vals (nnz) = CSR values of alpha * stiffness + beta * mass; every entry of a row with
- * at least one element is written exactly once (vals need not be initialised). */
+ * at least one element is written exactly once (vals need not be initialised).
+ * fq != NULL: the same launch also writes the load vector fout[n_verts] = sum_e sum_q
+ * fq[e][q] phi_i(x_q) dx_q from the user's source values fq (n_elems, Q) in ORIGINAL element
+ * order (abstract_basis.py:95-112; every entry written once, 0 for a vertex without
+ * elements). */
 int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
                            double alpha, double beta, const void *plan_device,
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,
-                           void *stream);
+                           const void *fq, int64_t n_elems, void *fout, void *stream);
 
 #ifdef __cplusplus
 }

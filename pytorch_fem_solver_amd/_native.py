@@ -86,7 +86,7 @@ SIGNATURES = {
     "tfem_p1_assemble_rings": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
-         c_int64, c_void_p],
+         c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "tfem_csr_to_dense": (
         c_int,

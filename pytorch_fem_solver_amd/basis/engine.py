@@ -176,6 +176,7 @@ def unpack_ring_plan(blob, layout):
         "rows": view(1, np.uint32, z[7] * z[1]),
         "rowstart": view(2, np.int32, z[1]),
         "vert_gid": view(3, np.int32, z[2]),
+        "row_elems": np.frombuffer(blob, dtype=np.uint32, count=z[6] * z[1], offset=z[15]),
     }
 
 
@@ -382,22 +383,28 @@ class AssemblyEngine:
             )
         return vals
 
-    def _assemble_rings(self, alpha, beta):
-        """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass."""
+    def _assemble_rings(self, alpha, beta, fq=None):
+        """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass and,
+        with source values fq (E, Q), the load vector."""
         d = self._inputs()
         rings = self.ring_plan()
         nnz = int(self.csr_structure()[1].shape[0])
         # rows of vertices without elements are empty, every other entry is written once
         vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+        fout = None
+        if fq is not None:
+            fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
+            fout = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_p1_assemble_rings(
                     _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
                     float(alpha), float(beta), _native.ptr(rings["blob"]),
-                    c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz, self._stream(),
+                    c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
+                    _native.ptr(fq), self.n_elems, _native.ptr(fout), self._stream(),
                 )
             )
-        return vals
+        return (vals, fout) if fq is not None else vals
 
     def _assemble_tiles(self, alpha, beta, want_matrix, fq):
         """One tfem_p1_assemble_tiles launch: CSR values and/or the load vector."""
@@ -424,7 +431,10 @@ class AssemblyEngine:
 
     def assemble_system(self, alpha, beta, fq):
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
-        values fq (E, Q): one fused launch on the tile path, two launches otherwise."""
+        values fq (E, Q): one fused launch on the ring and tile paths, two launches
+        otherwise."""
+        if self.ring_plan() is not None:
+            return self._assemble_rings(alpha, beta, fq)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
         return self.bilinear(alpha, beta), self.load(fq)

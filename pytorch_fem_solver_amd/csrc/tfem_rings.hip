@@ -37,6 +37,7 @@ constexpr int kRingWaves = kRingBlock / 64;
 constexpr int kRingVertCap = 1024;          // 10-bit local ids
 
 typedef unsigned int ru32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ru32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
 using ring_rsrc_t = __amdgpu_buffer_rsrc_t;
 
@@ -49,12 +50,15 @@ struct RingArgs {
   const T *coords;
   const unsigned char *plan;
   T *vals;
-  unsigned coords_bytes, plan_bytes, vals_bytes;
-  unsigned off_desc, off_rows, off_rowstart, off_gid;
+  const T *fq;  // (n_elems, Q) source values, load vector only
+  T *fout;
+  unsigned coords_bytes, plan_bytes, vals_bytes, fq_bytes, fout_bytes;
+  unsigned off_desc, off_rows, off_rowstart, off_gid, off_elems;
   int n_tiles;
   int lds_vert;   // vertex slots reserved in LDS
   T stiff_w;      // alpha * sum_q w_q / 2
   T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
+  T lamw[3][kMaxQuad];  // l_i(q) * w_q / 2 by local vertex i (load vector)
   int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 256 stamps
   unsigned long long *stamps;  // ablation build, flag 256: 8 cycle sums per wave
@@ -136,9 +140,10 @@ __device__ __forceinline__ T flag_weight(T w, uint32_t flag) {
 // that closes the fan (i + 1 == k) the second one belongs to slot 0 and is moved there at the
 // end (slots i >= k carry flag 0 and contribute nothing).  No branches: the reciprocal chains
 // of the slots interleave.
-template <typename T, int SLOTS, bool MASS>
+template <typename T, int SLOTS, bool MASS, bool DETS>
 __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLOTS> &rec,
-                                         uint32_t lv, const T *xy, T (&off)[SLOTS + 1], T &diag) {
+                                         uint32_t lv, const T *xy, T (&off)[SLOTS + 1], T &diag,
+                                         T (&sdets)[SLOTS]) {
   const int k = rec.k();
   T xv, yv, px, py;
   lds_xy(xy, lv, xv, yv);
@@ -162,12 +167,15 @@ __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLO
     const T cs = flag_weight<T>(a.stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
     off[i] = off[i] + cs * (p - qn);
     off[i + 1] = off[i + 1] + cs * (p - qc);
-    if (MASS) {
+    if (MASS || DETS) {
       const T sdet = flag_weight<T>(T(1), flag) * cross;  // signed determinant, 0 without triangle
-      const T m = a.mass_o * sdet;
-      off[i] = off[i] + m;
-      off[i + 1] = off[i + 1] + m;
-      dsum = dsum + sdet;
+      if (DETS) sdets[i] = sdet;
+      if (MASS) {
+        const T m = a.mass_o * sdet;
+        off[i] = off[i] + m;
+        off[i + 1] = off[i + 1] + m;
+        dsum = dsum + sdet;
+      }
     }
     ecx = enx;
     ecy = eny;
@@ -389,11 +397,45 @@ __device__ __forceinline__ void ring_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename T, int SLOTS, bool MASS, bool CHUNK, bool DBG>
+// Q source values of one element (load vector): 16-byte loads where the type allows.
+template <typename T, int QL>
+__device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v)[QL > 0 ? QL : 1]) {
+#pragma unroll
+  for (int q = 0; q + 1 < QL; q += 2) {
+    if constexpr (sizeof(T) == 8) {
+      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, 0);
+      v[q] = __builtin_bit_cast(double, ru32x2{x.x, x.y});
+      v[q + 1] = __builtin_bit_cast(double, ru32x2{x.z, x.w});
+    } else {  // two dword loads: raw_buffer_load_b64 is miscompiled by this hipcc (tfem_tiles.hip)
+      v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte + unsigned(q) * 4u, 0, 0));
+      v[q + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte + unsigned(q) * 4u + 4u, 0, 0));
+    }
+  }
+  if (QL & 1) {
+    const unsigned o = byte + unsigned(QL - 1) * unsigned(sizeof(T));
+    if constexpr (sizeof(T) == 8) {
+      const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0);
+      const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(r, o + 4u, 0, 0);
+      v[QL > 0 ? QL - 1 : 0] = __builtin_bit_cast(double, ru32x2{lo, hi});
+    } else {
+      v[QL > 0 ? QL - 1 : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
+    }
+  }
+}
+
+// QL = 0: matrix only.  QL = Q > 0: the launch also forms the load vector
+//   f_v = sum over the triangles T of the fan  det_T * sum_q fq[T][q] l_loc(q) w_q / 2
+// (abstract_basis.py:95-112 with basis.py:93-96): per slot the element id and the local index
+// `loc` of v in it come from the plan's row_elems, the Q source values are gathered while the
+// matrix part of the row is computed, l_loc(q) w_q / 2 is a 3 x Q table in LDS.
+template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG>
 __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
+  constexpr bool LOAD = QL > 0;
+  constexpr int kQPad = (QL + 1) & ~1;  // table row pitch: 16-byte aligned rows
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
   T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
+  T *lam_tab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [3][kQPad]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,10 +452,15 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
   const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
   const ring_rsrc_t r_vals = ring_rsrc(a.vals, a.vals_bytes);
+  const ring_rsrc_t r_fq = ring_rsrc(a.fq, a.fq_bytes);
+  const ring_rsrc_t r_fout = ring_rsrc(a.fout, a.fout_bytes);
   constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
+  if (LOAD && tid < 3 * kQPad) lam_tab[tid] = (tid % kQPad) < QL ? a.lamw[tid / kQPad][tid % kQPad] : T(0);
 
   RingRec<SLOTS> rec, rec_ld;
+  uint32_t se[LOAD ? SLOTS : 1], se_ld[LOAD ? SLOTS : 1];  // row_elems of the row (load vector)
+  unsigned gid_row = 0;                                    // vertex of this lane's current row
   int rowstart = 0, rowstart_ld = 0;
   unsigned gid_own = 0, gid_halo = 0;        // vertex ids of the tile whose coordinates load next
   unsigned gid_own_ld = 0, gid_halo_ld = 0;  // ... and of the tile after it
@@ -439,6 +486,21 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
       ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
       if (!CHUNK)
         rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
+      if (LOAD) {  // SLOTS dwords per row: 16-byte pieces and one 12-byte piece
+        const unsigned eb = a.off_elems + row * unsigned(4 * SLOTS);
+#pragma unroll
+        for (int i = 0; i + 4 <= SLOTS; i += 4) {
+          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, eb + unsigned(4 * i), 0, 0);
+          se_ld[i] = v.x;
+          se_ld[i + 1] = v.y;
+          se_ld[i + 2] = v.z;
+          se_ld[i + 3] = v.w;
+        }
+        const ru32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r_plan, eb + unsigned(4 * (SLOTS - 3)), 0, 0);
+        se_ld[LOAD ? SLOTS - 3 : 0] = v.x;
+        se_ld[LOAD ? SLOTS - 2 : 0] = v.y;
+        se_ld[LOAD ? SLOTS - 1 : 0] = v.z;
+      }
     }
     if (!(DBG && (a.flags & 4))) {
       ring_load_xy<T>(r_coords, g_own, own_ld[0], own_ld[1]);
@@ -473,6 +535,9 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   park(dc, xy);
   rec = rec_ld;
   rowstart = rowstart_ld;
+  gid_row = gid_own;
+#pragma unroll
+  for (int i = 0; i < (LOAD ? SLOTS : 1); ++i) se[i] = se_ld[i];
   gid_own = gid_own_ld;
   gid_halo = gid_halo_ld;
   __syncthreads();
@@ -490,11 +555,21 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     }
     if (timing) t1 = ring_stamp();
     // ---- B ----
-    T off[SLOTS + 1], diag;
+    T off[SLOTS + 1], diag, sdets[SLOTS];
+    T fqv[LOAD ? SLOTS : 1][QL > 0 ? QL : 1];
+    uint32_t locs = 0;  // 2 bits per slot: local index of the row's vertex in the slot's element
+    if (LOAD) {  // the source values of the fan's elements: in flight during the matrix part
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const uint32_t e = se[i] & 0x3FFFFFFFu;
+        ring_load_fq<T, QL>(r_fq, e != 0x3FFFFFFFu ? e * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u, fqv[i]);
+        locs |= (se[i] >> 30) << (2 * i);
+      }
+    }
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
-      ring_row<T, SLOTS, MASS>(a, rec, unsigned(my_row < dc.row1 ? my_row : 0),
-                               xy + cur * 2 * a.lds_vert, off, diag);
+      ring_row<T, SLOTS, MASS, LOAD>(a, rec, unsigned(my_row < dc.row1 ? my_row : 0),
+                                     xy + cur * 2 * a.lds_vert, off, diag, sdets);
     } else {
       diag = T(1);
 #pragma unroll
@@ -506,6 +581,17 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     }
     int total = 0, pre = 0;
     if (!(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+    T facc = T(0);
+    if (LOAD) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const T *w = lam_tab + ((locs >> (2 * i)) & 3u) * kQPad;
+        T sq = T(0);
+#pragma unroll
+        for (int q = 0; q < QL; ++q) sq = sq + fqv[i][q] * w[q];
+        facc = facc + sdets[i] * sq;
+      }
+    }
     const int kk = rec.k();
     const int len_c = kk > 0 ? kk + 1 : 0;
     if (timing) {
@@ -528,6 +614,13 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
         ring_store<T, SLOTS, DBG>(my_stage, total, pre, rowstart, len_c, r_vals, a.flags);
       }
     }
+    if (LOAD && dc.row0 + lane < dc.row1) {
+      const unsigned byte = gid_row * unsigned(sizeof(T));
+      if constexpr (sizeof(T) == 8)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, facc), r_fout, byte, 0, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, facc), r_fout, byte, 0, 0);
+    }
     if (timing) {
       t6 = ring_stamp();
       tsum[0] += t1 - t0;  // A load issue
@@ -541,6 +634,9 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     if (t_n < 0) break;
     rec = rec_ld;
     rowstart = rowstart_ld;
+    gid_row = gid_own;
+#pragma unroll
+    for (int i = 0; i < (LOAD ? SLOTS : 1); ++i) se[i] = se_ld[i];
     gid_own = gid_own_ld;
     gid_halo = gid_halo_ld;
     // ---- E ----
@@ -572,6 +668,9 @@ struct RingLaunch {
   int64_t n_verts, nnz;
   void *vals;
   hipStream_t stream;
+  const void *fq = nullptr;  // nullptr: no load vector
+  int64_t n_elems = 0;
+  void *fout = nullptr;
   int blocks_per_cu = 0;  // > 0: cap on resident workgroups per CU (tuning)
   int flags = 0;          // > 0: ablation build (wrong results by design)
   unsigned long long *stamps = nullptr;
@@ -590,16 +689,29 @@ static int ring_cu_count() {
   return cached;
 }
 
-template <typename T, int SLOTS, bool MASS>
-static void *pick_ring_chunk(bool chunk) {
-  return chunk ? reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, true, false>)
-               : reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, false, false>);
+template <typename T, int SLOTS, bool MASS, bool CHUNK>
+static void *pick_ring_q(int nq) {
+  switch (nq) {
+    case 0: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 0, false>);
+    case 1: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 1, false>);
+    case 3: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 3, false>);
+    case 4: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 4, false>);
+    case 6: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 6, false>);
+    default: return nullptr;
+  }
 }
 
+template <typename T, int SLOTS, bool MASS>
+static void *pick_ring_chunk(bool chunk, int nq) {
+  return chunk ? pick_ring_q<T, SLOTS, MASS, true>(nq) : pick_ring_q<T, SLOTS, MASS, false>(nq);
+}
+
+// nq = 0: matrix only
 template <typename T>
-static void *pick_ring_kernel(int slots, bool mass, bool chunk) {
-  if (slots == 7) return mass ? pick_ring_chunk<T, 7, true>(chunk) : pick_ring_chunk<T, 7, false>(chunk);
-  return mass ? pick_ring_chunk<T, 15, true>(chunk) : pick_ring_chunk<T, 15, false>(chunk);
+static void *pick_ring_kernel(int slots, bool mass, bool chunk, int nq) {
+  if (slots == 7)
+    return mass ? pick_ring_chunk<T, 7, true>(chunk, nq) : pick_ring_chunk<T, 7, false>(chunk, nq);
+  return mass ? pick_ring_chunk<T, 15, true>(chunk, nq) : pick_ring_chunk<T, 15, false>(chunk, nq);
 }
 
 template <typename T>
@@ -609,7 +721,9 @@ static int launch_rings(const RingLaunch &L) {
     return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   const int64_t *z = L.layout;
   if (z[0] == 0) return TFEM_OK;
-  if (!L.coords || !L.plan || !L.vals) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const bool load = L.fq != nullptr;
+  if (!L.coords || !L.plan || !L.vals || (load && !L.fout))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] || z[14] > kRingHaloCap ||
       !((z[6] == 7 && z[7] == 4) || (z[6] == 15 && z[7] == 8)) || z[5] > z[6] + 1)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "ring plan exceeds the kernel's capacities");
@@ -619,7 +733,8 @@ static int launch_rings(const RingLaunch &L) {
   a.plan = L.plan;
   a.vals = static_cast<T *>(L.vals);
   const int64_t rb = int64_t(sizeof(T));
-  const int64_t extents[3] = {L.n_verts * 2 * rb, z[12], L.nnz * rb};
+  const int64_t extents[5] = {L.n_verts * 2 * rb, z[12], L.nnz * rb,
+                              load ? L.n_elems * tables.nq * rb : 0, load ? L.n_verts * rb : 0};
   for (int64_t e : extents)
     if (e < 0 || e >= (int64_t(1) << 32))
       return fail(TFEM_ERR_INDEX_RANGE, "an array of %lld bytes does not fit the 32-bit offsets "
@@ -627,6 +742,13 @@ static int launch_rings(const RingLaunch &L) {
   a.coords_bytes = unsigned(extents[0]);
   a.plan_bytes = unsigned(extents[1]);
   a.vals_bytes = unsigned(extents[2]);
+  a.fq = static_cast<const T *>(L.fq);
+  a.fout = static_cast<T *>(L.fout);
+  a.fq_bytes = unsigned(extents[3]);
+  a.fout_bytes = unsigned(extents[4]);
+  a.off_elems = unsigned(z[15]);
+  for (int i = 0; i < 3; ++i)
+    for (int q = 0; q < tables.nq; ++q) a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
   a.off_desc = unsigned(z[8]);
   a.off_rows = unsigned(z[9]);
   a.off_rowstart = unsigned(z[10]);
@@ -648,15 +770,22 @@ static int launch_rings(const RingLaunch &L) {
   const bool mass = L.beta != 0.0;
   const int slots = int(z[6]);
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
-                     size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T);
+                     size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) +
+                     (load ? size_t(3 * ((tables.nq + 1) & ~1)) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
-  void *kernel = pick_ring_kernel<T>(slots, mass, chunk);
+  void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0);
+  if (!kernel) return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   if constexpr (sizeof(T) == 8) {  // the ablation build exists for fp64 stiffness, 7 slots
-    if (L.flags > 0 && slots == 7 && !mass)
-      kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, true>)
-                     : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, true>);
+    if (L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {
+      if (load)
+        kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 4, true>)
+                       : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, 4, true>);
+      else
+        kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 0, true>)
+                       : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, 0, true>);
+    }
   }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -692,13 +821,16 @@ int tfem_ring_capacity(int what) {
 int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
                            double alpha, double beta, const void *plan_device,
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,
-                           void *stream) {
+                           const void *fq, int64_t n_elems, void *fout, void *stream) {
   using namespace tfem;
   if (real_bytes != 4 && real_bytes != 8)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
   if (!plan_layout_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_layout_host is NULL");
   RingLaunch L{coords, quad_order, alpha, beta, static_cast<const unsigned char *>(plan_device),
                plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
+  L.fq = fq;
+  L.n_elems = n_elems;
+  L.fout = fout;
   // developer switches (tools/time_rings.py)
   if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
   if (const char *v = std::getenv("TFEM_RINGS_DEBUG")) L.flags = std::atoi(v);
@@ -709,13 +841,17 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
 // 64-bit words or NULL.
 int tfem_p1_rings_debug(const void *coords, int64_t n_verts, int quad_order, const void *plan_device,
                         const int64_t *plan_layout_host, void *vals, int64_t nnz, void *stream,
-                        int flags, int blocks_per_cu, unsigned long long *stamps) {
+                        int flags, int blocks_per_cu, unsigned long long *stamps, const void *fq,
+                        int64_t n_elems, void *fout) {
   using namespace tfem;
   RingLaunch L{coords, quad_order, 1.0, 0.0, static_cast<const unsigned char *>(plan_device),
                plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
   L.flags = flags;
   L.blocks_per_cu = blocks_per_cu;
   L.stamps = stamps;
+  L.fq = fq;
+  L.n_elems = n_elems;
+  L.fout = fout;
   return launch_rings<double>(L);
 }
 

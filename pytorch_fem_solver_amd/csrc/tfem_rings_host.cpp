@@ -48,6 +48,9 @@ struct RingPlan {
   std::vector<int32_t> desc;
   std::vector<uint32_t> rows;     // `words` dwords per owned row
   std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
+  // load vector only: per owned row `slots` words = element of every slot's triangle |
+  // local index of the row's vertex in it << 30 (0x3FFFFFFF: no triangle)
+  std::vector<uint32_t> row_elems;
   std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
   int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0, max_n_halo = 0;
   int64_t n_tiles = 0;
@@ -70,6 +73,8 @@ struct Fan {
   int k = 0;
   int32_t nb[16];   // neighbours in fan order (global ids)
   int flag[16];     // triangle flag of every slot
+  int32_t elem[16]; // element of every slot's triangle (-1: none)
+  int loc[16];      // local index of the fan's vertex inside that element
 };
 
 // Fan of vertex v from its incident elements.  Returns false when the fan has no ring form.
@@ -81,6 +86,7 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
   if (nt == 0) return true;
   if (nt > 16) return false;
   int32_t ta[16], tb[16];   // triangle t = (v, ta, tb) in connectivity order (rotated)
+  int tj[16];               // local index of v in triangle t
   int32_t nb[17];
   int cnt[17], tri[17][2];
   int n_nb = 0;
@@ -93,6 +99,7 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
         ++hits;
       }
     if (hits != 1) return false;  // degenerate element
+    tj[t] = j;
     ta[t] = int32_t(c[(j + 1) % 3]);
     tb[t] = int32_t(c[(j + 2) % 3]);
     if (ta[t] == tb[t]) return false;
@@ -127,6 +134,8 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
       seen[c] = true;
       fan.nb[fan.k] = nb[c];
       fan.flag[fan.k] = 0;
+      fan.elem[fan.k] = -1;
+      fan.loc[fan.k] = 0;
       int t = -1;
       for (int s = 0; s < cnt[c]; ++s)
         if (!used[tri[c][s]]) {
@@ -140,6 +149,8 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
       used[t] = true;
       const bool forward = ta[t] == nb[c];
       fan.flag[fan.k] = forward ? 1 : 2;
+      fan.elem[fan.k] = adj_first[t];
+      fan.loc[fan.k] = tj[t];
       ++fan.k;
       const int o = index_of(forward ? tb[t] : ta[t]);
       if (seen[o]) return o;  // closed the cycle: slot k-1 links to the start
@@ -292,6 +303,10 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       }
       plan.rows.insert(plan.rows.end(), w, w + plan.words);
       plan.rowstart.push_back(int32_t(rowptr[u]));
+      for (int i = 0; i < plan.slots; ++i)
+        plan.row_elems.push_back(i < fan.k && fan.flag[i] != 0
+                                     ? uint32_t(fan.elem[i]) | uint32_t(fan.loc[i]) << 30
+                                     : 0x3FFFFFFFu);
     }
     int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
                                   wave_start[1], wave_start[2], wave_start[3], n_own,
@@ -311,6 +326,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.desc.clear();
     plan.rows.clear();
     plan.rowstart.clear();
+    plan.row_elems.clear();
     plan.vert_gid.clear();
     plan.max_n_vert = plan.max_n_own = plan.max_n_halo = 0;
     std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
@@ -452,11 +468,12 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[4] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
-                            int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4};
+  const int64_t bytes[5] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+                            int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
+                            int64_t(p.row_elems.size()) * 4};
   int64_t off = 0;
-  for (int i = 0; i < 4; ++i) {
-    layout[8 + i] = off;
+  for (int i = 0; i < 5; ++i) {
+    layout[i < 4 ? 8 + i : 15] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
   layout[12] = off + 64;
@@ -482,7 +499,7 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
   if (own_cap < 1 || own_cap > 256 || vert_cap < 17 || vert_cap > 1024 || own_cap > vert_cap)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad tile capacities");
-  if (3 * n_elems >= (int64_t(1) << 31) || rowptr_host[n_verts] >= (int64_t(1) << 31))
+  if (n_elems >= (int64_t(1) << 30) - 1 || rowptr_host[n_verts] >= (int64_t(1) << 31))
     return fail(TFEM_ERR_INDEX_RANGE, "mesh too large for the int32 ring plan");
   auto *plan = new RingPlan();
   // developer switch: TFEM_RING_TILES=zorder disables the consecutive-vertex tiles
@@ -521,6 +538,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   std::memcpy(out + layout[9], p->rows.data(), p->rows.size() * 4);
   std::memcpy(out + layout[10], p->rowstart.data(), p->rowstart.size() * 4);
   std::memcpy(out + layout[11], p->vert_gid.data(), p->vert_gid.size() * 4);
+  std::memcpy(out + layout[15], p->row_elems.data(), p->row_elems.size() * 4);
   return TFEM_OK;
 }
 

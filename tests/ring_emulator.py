@@ -29,15 +29,18 @@ def decode_rows(rows, slots):
     return {"id": ids, "flag": flag, "pos": pos, "k": k.astype(np.int64), "dpos": dpos.astype(np.int64)}
 
 
-def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0):
-    """Returns (vals, writes): CSR values of stiff_w-weighted stiffness + mass and how often
-    every CSR entry was written."""
+def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=None, lamw=None):
+    """Returns (vals, writes, covered[, f]): CSR values of stiff_w-weighted stiffness + mass,
+    how often every CSR entry was written, the number of rows covered and -- with source
+    values fq (E, Q) and the table lamw (3, Q) = l_i(q) w_q / 2 -- the load vector."""
     slots, words = plan["slots"], plan["words"]
     desc = plan["desc"].reshape(-1, 16)
     rows = plan["rows"].reshape(-1, words)
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
+    fvec = np.full(coords.shape[0], np.nan) if fq is not None else None
+    row_elems = plan["row_elems"].reshape(-1, slots)
     for d in desc:
         vert_off, n_vert, row_off, ws0, ws1, ws2, ws3, n_own = (int(x) for x in d[:8])
         wave_start = [ws0, ws1, ws2, ws3, n_own]
@@ -60,26 +63,39 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0):
         for r in range(n_own):
             k = int(rec["k"][r])
             if k == 0:
+                if fvec is not None:
+                    fvec[gid[r]] = 0.0
                 continue
             ids, flag, pos = rec["id"][r], rec["flag"][r], rec["pos"][r]
             assert ids[:k].max() < n_vert and np.all(ids[:k] != r)
             e = xy[ids[:k]] - xy[r]
             off = np.zeros(k)
             diag = 0.0
+            facc = 0.0
+            se = row_elems[row_off + r]
+            assert np.all(se[k:] == 0x3FFFFFFF)
             for i in range(k):
                 nxt = 0 if i + 1 == k else i + 1
                 if flag[i] == 0:
+                    assert se[i] == 0x3FFFFFFF
                     continue
-                d = e[nxt] - e[i]
+                dvec = e[nxt] - e[i]
                 cross = e[i, 0] * e[nxt, 1] - e[i, 1] * e[nxt, 0]
                 sdet = cross if flag[i] == 1 else -cross
                 cs = stiff_w / sdet
-                diag += cs * d.dot(d) + mass_d * sdet
-                off[i] += -cs * d.dot(e[nxt]) + mass_o * sdet
-                off[nxt] += cs * d.dot(e[i]) + mass_o * sdet
+                diag += cs * dvec.dot(dvec) + mass_d * sdet
+                off[i] += -cs * dvec.dot(e[nxt]) + mass_o * sdet
+                off[nxt] += cs * dvec.dot(e[i]) + mass_o * sdet
+                if fvec is not None:
+                    elem, loc = int(se[i] & 0x3FFFFFFF), int(se[i] >> 30)
+                    facc += sdet * float(np.dot(fq[elem], lamw[loc]))
             targets = np.concatenate([rowstart[r] + pos[:k], [rowstart[r] + rec["dpos"][r]]])
             assert np.unique(targets).size == k + 1
             assert targets.max() < rowstart[r] + k + 1
             vals[targets] = np.concatenate([off, [diag]])
             writes[targets] += 1
+            if fvec is not None:
+                fvec[gid[r]] = facc
+    if fvec is not None:
+        return vals, writes, covered, fvec
     return vals, writes, covered

@@ -166,12 +166,19 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
     if form == "stiffness_mass":
         md = float((0.5 * weights * bary[:, 0] * bary[:, 0]).sum())
         mo = float((0.5 * weights * bary[:, 0] * bary[:, 1]).sum())
-    vals, writes, covered = run_ring_plan(plan, mesh["vertices"], colind.shape[0], w, md, mo)
+    lamw = (bary * (0.5 * weights)[:, None]).T  # (3, Q): l_i(q) w_q / 2
+    fl, geo = orc.p1_assemble(mesh["vertices"], mesh["triangles"], 3, "load")
+    fq = orc.source_sin_sin(geo["integration_points"])[..., 0, 0]
+    vals, writes, covered, fvec = run_ring_plan(plan, mesh["vertices"], colind.shape[0], w, md, mo,
+                                                fq=fq, lamw=lamw)
     assert covered == nv
     assert (writes == 1).all()
     local, _ = orc.p1_assemble(mesh["vertices"], mesh["triangles"], 3, form)
     want = orc.assemble_csr_values(local, slots.reshape(-1, 3, 3), colind.shape[0])
     assert scaled_error(vals, want) <= 1e-13
+    # the load vector through the plan's row_elems (element and local index per slot)
+    want_f = orc.assemble_linear(fl, mesh["triangles"], nv).reshape(-1)
+    assert scaled_error(fvec, want_f) <= 1e-13
 
 
 def test_ring_plan_open_fans_and_isolated_vertices():

@@ -1,0 +1,64 @@
+"""Summarise rocprofv3 output of `bench.py` for the committed profiles/ files.
+
+    python tools/summarize_pmc.py --stats gpurun_out/prof --pmc gpurun_out/pmc/p1 gpurun_out/pmc/p2 ... \
+        --kernel k_p1_rings --out profiles/r01_bench_pmc_summary.json --n 2236 --order 3
+
+Per kernel instantiation whose name contains --kernel: mean of every collected counter per
+dispatch, mean duration (kernel trace of the PMC passes), and the HBM traffic per launch by
+the rule of MI355X_MICROARCH.md (HBM section): FETCH_SIZE (KB) counts half of the fetched
+bytes on gfx950 -> doubled; WRITE_SIZE (KB) exact; cross-check TCC_MISS_sum x 128 B.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+p = argparse.ArgumentParser()
+p.add_argument("--pmc", nargs="+", required=True, help="output directories of the --pmc passes")
+p.add_argument("--kernel", default="k_p1_rings")
+p.add_argument("--out", required=True)
+p.add_argument("--n", type=int, default=2236)
+p.add_argument("--order", type=int, default=3)
+p.add_argument("--command", default="")
+args = p.parse_args()
+
+counters = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
+durations = defaultdict(list)
+for d in args.pmc:
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            seen = set()
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                if args.kernel not in name:
+                    continue
+                counters[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                key = (name, row["Dispatch_Id"])
+                if key not in seen:
+                    seen.add(key)
+                    durations[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+
+out = {"command": args.command, "workload": {"n": args.n, "order": args.order}, "kernels": {}}
+for name, cs in counters.items():
+    entry = {"counters_per_dispatch": {c: {"dispatches": len(v), "mean": sum(v) / len(v)} for c, v in sorted(cs.items())}}
+    ds = durations[name]
+    entry["kernel_us_under_pmc"] = {"n": len(ds), "mean": sum(ds) / len(ds)}
+    mean = lambda c: (sum(cs[c]) / len(cs[c])) if c in cs else None  # noqa: E731
+    if mean("FETCH_SIZE") is not None and mean("WRITE_SIZE") is not None:
+        fetch = 2.0 * mean("FETCH_SIZE") * 1024.0
+        write = mean("WRITE_SIZE") * 1024.0
+        entry["hbm_traffic_bytes_per_launch"] = {
+            "rule": "MI355X_MICROARCH.md HBM section: FETCH_SIZE (KB) counts half of the fetched bytes "
+                    "on gfx950 -> doubled; WRITE_SIZE (KB) exact",
+            "fetch_bytes_corrected": fetch,
+            "write_bytes": write,
+            "total": fetch + write,
+        }
+        if mean("TCC_MISS_sum") is not None:
+            entry["hbm_traffic_bytes_per_launch"]["cross_check_TCC_MISS_x128B"] = mean("TCC_MISS_sum") * 128.0
+    out["kernels"][name] = entry
+with open(args.out, "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps({k: v.get("hbm_traffic_bytes_per_launch", {}).get("total") for k, v in out["kernels"].items()}, indent=1))

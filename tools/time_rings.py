@@ -104,7 +104,7 @@ if "rings" in args.kernels:
             _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
                              _native.ptr(rings["blob"]), ctypes.c_void_p(rings["layout"].ctypes.data),
                              _native.ptr(vals), ctypes.c_int64(nnz), _native.current_stream(eng.device),
-                             256 | extra, per_cu, _native.ptr(stamps)))
+                             256 | extra, per_cu, _native.ptr(stamps), None, ctypes.c_int64(0), None))
             torch.cuda.synchronize()
             t = stamps.cpu().numpy().reshape(-1, 8)
             t = t[t[:, 7] > 0]
