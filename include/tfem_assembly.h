@@ -246,6 +246,21 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,
                            const void *fq, int64_t n_elems, void *fout, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Interface exchange of the multi-GPU sharding (DEVICE; the path shards by element
+ * range, DoFs on an inter-rank interface are summed with one all-reduce of a packed
+ * buffer: SURVEY 8(e); the reference is single-process).  pack: buf (nbuf) is zeroed,
+ * then buf[k_pos[i]] = vals[k_idx[i]] (i < nk) and buf[f_pos[i]] = f[f_idx[i]] (i < nf);
+ * unpack: the reverse copies.  vals / f may be NULL (that part is skipped); index arrays
+ * are int64 device arrays.  One kernel launch each.
+ * ------------------------------------------------------------------------- */
+int tfem_interface_pack(const void *vals, const void *f, int real_bytes, const int64_t *k_idx,
+                        const int64_t *k_pos, int64_t nk, const int64_t *f_idx, const int64_t *f_pos,
+                        int64_t nf, void *buf, int64_t nbuf, void *stream);
+int tfem_interface_unpack(void *vals, void *f, int real_bytes, const int64_t *k_idx,
+                          const int64_t *k_pos, int64_t nk, const int64_t *f_idx,
+                          const int64_t *f_pos, int64_t nf, const void *buf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,16 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
          c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "tfem_interface_pack": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_int64, c_void_p],
+    ),
+    "tfem_interface_unpack": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+         c_void_p, c_void_p],
+    ),
     "tfem_csr_to_dense": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p],

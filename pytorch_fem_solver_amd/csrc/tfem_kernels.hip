@@ -560,6 +560,33 @@ using namespace tfem;
        ? (idx_bytes == 4 ? FN<double, int32_t>(__VA_ARGS__) : FN<double, int64_t>(__VA_ARGS__)) \
        : (idx_bytes == 4 ? FN<float, int32_t>(__VA_ARGS__) : FN<float, int64_t>(__VA_ARGS__)))
 
+// Interface exchange of the element-range sharding (parallel.py): entries of the local CSR
+// values / local vector that belong to DoFs shared with another rank are copied into the
+// packed buffer the ranks all-reduce (pack) and back (unpack).  One launch each.
+template <typename T>
+__global__ void k_interface_pack(const T *vals, const T *f, const int64_t *k_idx, const int64_t *k_pos,
+                                 int64_t nk, const int64_t *f_idx, const int64_t *f_pos, int64_t nf,
+                                 T *buf) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < nk) {
+    if (vals) buf[k_pos[i]] = vals[k_idx[i]];
+  } else if (i < nk + nf) {
+    if (f) buf[f_pos[i - nk]] = f[f_idx[i - nk]];
+  }
+}
+
+template <typename T>
+__global__ void k_interface_unpack(T *vals, T *f, const int64_t *k_idx, const int64_t *k_pos,
+                                   int64_t nk, const int64_t *f_idx, const int64_t *f_pos, int64_t nf,
+                                   const T *buf) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < nk) {
+    if (vals) vals[k_idx[i]] = buf[k_pos[i]];
+  } else if (i < nk + nf) {
+    if (f) f[f_idx[i - nk]] = buf[f_pos[i - nk]];
+  }
+}
+
 extern "C" {
 
 int tfem_device_count(void) {
@@ -691,6 +718,51 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
     hipLaunchKernelGGL(k_csr_to_dense<float>, dim3(blocks_for(n_dofs)), dim3(kBlock), 0, s,
                        rowptr, colind, static_cast<const float *>(vals), n_dofs,
                        static_cast<float *>(dense));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_interface_pack(const void *vals, const void *f, int real_bytes, const int64_t *k_idx,
+                        const int64_t *k_pos, int64_t nk, const int64_t *f_idx, const int64_t *f_pos,
+                        int64_t nf, void *buf, int64_t nbuf, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (nk < 0 || nf < 0 || nbuf < 0 || (nbuf > 0 && !buf) || (nk > 0 && (!k_idx || !k_pos)) ||
+      (nf > 0 && (!f_idx || !f_pos)))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (nbuf == 0) return TFEM_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // positions this rank does not share stay zero: the neutral element of the all-reduce
+  TFEM_HIP_CHECK(hipMemsetAsync(buf, 0, size_t(nbuf) * size_t(real_bytes), s));
+  if (nk + nf == 0) return TFEM_OK;
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_interface_pack<double>, dim3(blocks_for(nk + nf)), dim3(kBlock), 0, s,
+                       static_cast<const double *>(vals), static_cast<const double *>(f), k_idx, k_pos,
+                       nk, f_idx, f_pos, nf, static_cast<double *>(buf));
+  else
+    hipLaunchKernelGGL(k_interface_pack<float>, dim3(blocks_for(nk + nf)), dim3(kBlock), 0, s,
+                       static_cast<const float *>(vals), static_cast<const float *>(f), k_idx, k_pos,
+                       nk, f_idx, f_pos, nf, static_cast<float *>(buf));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_interface_unpack(void *vals, void *f, int real_bytes, const int64_t *k_idx,
+                          const int64_t *k_pos, int64_t nk, const int64_t *f_idx,
+                          const int64_t *f_pos, int64_t nf, const void *buf, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (nk < 0 || nf < 0 || (nk + nf > 0 && !buf) || (nk > 0 && (!k_idx || !k_pos)) ||
+      (nf > 0 && (!f_idx || !f_pos)))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (nk + nf == 0) return TFEM_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_interface_unpack<double>, dim3(blocks_for(nk + nf)), dim3(kBlock), 0, s,
+                       static_cast<double *>(vals), static_cast<double *>(f), k_idx, k_pos, nk, f_idx,
+                       f_pos, nf, static_cast<const double *>(buf));
+  else
+    hipLaunchKernelGGL(k_interface_unpack<float>, dim3(blocks_for(nk + nf)), dim3(kBlock), 0, s,
+                       static_cast<float *>(vals), static_cast<float *>(f), k_idx, k_pos, nk, f_idx,
+                       f_pos, nf, static_cast<const float *>(buf));
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

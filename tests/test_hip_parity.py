@@ -550,3 +550,48 @@ def test_linear_form_is_differentiable_like_the_reference():
     (g_ref,) = torch.autograd.grad(loss2, theta2)
     assert scaled_error(r.detach().cpu(), ref.detach().cpu()) <= TOL
     assert scaled_error(g_hip.cpu(), g_ref.cpu()) <= 1e-11
+
+
+def test_interface_pack_unpack_kernels():
+    """tfem_interface_pack / _unpack (the copies around the multi-GPU all-reduce) against the
+    same copies done with torch indexing; a one-rank exchange (all-reduce = identity) through
+    InterfaceExchange leaves vals and f unchanged."""
+    import ctypes
+
+    from pytorch_fem_solver_amd import _native, parallel
+
+    lib = _native.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vals = torch.rand(5000, generator=g)
+    f = torch.rand(700, generator=g)
+    nk, nf, nbuf = 311, 97, 600
+    k_idx = torch.randperm(5000, generator=g)[:nk]
+    f_idx = torch.randperm(700, generator=g)[:nf]
+    pos = torch.randperm(nbuf, generator=g)
+    k_pos, f_pos = pos[:nk].contiguous(), pos[nk:nk + nf].contiguous()
+    buf = torch.full((nbuf,), 7.0)
+    stream = _native.current_stream(buf.device)
+    _native.check(lib.tfem_interface_pack(_native.ptr(vals), _native.ptr(f), 8, _native.ptr(k_idx),
+                                          _native.ptr(k_pos), nk, _native.ptr(f_idx), _native.ptr(f_pos),
+                                          nf, _native.ptr(buf), nbuf, stream))
+    want = torch.zeros(nbuf)
+    want[k_pos] = vals[k_idx]
+    want[f_pos] = f[f_idx]
+    assert torch.equal(buf, want)
+    buf2 = torch.rand(nbuf, generator=g)
+    v2, f2 = vals.clone(), f.clone()
+    _native.check(lib.tfem_interface_unpack(_native.ptr(v2), _native.ptr(f2), 8, _native.ptr(k_idx),
+                                            _native.ptr(k_pos), nk, _native.ptr(f_idx), _native.ptr(f_pos),
+                                            nf, _native.ptr(buf2), stream))
+    vw, fw = vals.clone(), f.clone()
+    vw[k_idx] = buf2[k_pos]
+    fw[f_idx] = buf2[f_pos]
+    assert torch.equal(v2, vw) and torch.equal(f2, fw)
+    # NULL parts are skipped
+    _native.check(lib.tfem_interface_pack(None, _native.ptr(f), 8, _native.ptr(k_idx), _native.ptr(k_pos), nk,
+                                          _native.ptr(f_idx), _native.ptr(f_pos), nf, _native.ptr(buf), nbuf,
+                                          stream))
+    want = torch.zeros(nbuf)
+    want[f_pos] = f[f_idx]
+    assert torch.equal(buf, want)
+    assert ctypes.c_int(lib.tfem_interface_pack(None, None, 3, None, None, 0, None, None, 0, None, 0, None)).value == 1
