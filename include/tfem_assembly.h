@@ -99,6 +99,9 @@ int tfem_tri_geometry(const void *coords, int real_bytes, const void *conn, int 
  *   conn_geo  (n_elems, 3) vertex ids into coords (geometry)
  *   slots     (n_elems, n, n) from tfem_csr_symbolic_fill, n = 3 (P1) or 6 (P2)
  *   vals      (nnz) CSR values; OVERWRITTEN (zero-filled by this call, then summed)
+ *   slots == NULL: LOCAL-BLOCK mode -- vals (n*n, n_elems) receives the element blocks
+ *             entry-major (vals[(i*n+j) * n_elems + e] = local[e][i][j]), nnz = n*n*n_elems;
+ *             tfem_csr_gather then forms the CSR values without atomics.
  * Fracture variant (fracture_basis.py:20-26,189-197): if `frac_pinv` is not NULL
  * the elements are `n_fractures` consecutive groups of n_elems/n_fractures; the
  * reference gradients are post-multiplied by frac_pinv[f] (2x3) and dx by
@@ -129,7 +132,8 @@ int tfem_tri_load_vector(const void *coords, int real_bytes, const void *conn_ge
  *   bilinear  (m = n): adds into CSR vals through `slots`      (:87-91)
  *   linear    (m = 1): adds into out[conn_dof]                 (:106-110)
  *   functional(m = 1): writes out[e] = sum_k sum_q (n_inner = n, usually 1)  (:65-72)
- * `vals` / `out` are overwritten.
+ * `vals` / `out` are overwritten.  tfem_reduce_scatter_bilinear with slots == NULL works in
+ * LOCAL-BLOCK mode like tfem_tri_bilinear_csr.
  * ------------------------------------------------------------------------- */
 int tfem_reduce_scatter_bilinear(const void *integrand, int real_bytes, int64_t es, int64_t qs,
                                  const void *dx, int64_t n_elems, int n_quad, int n_local,
@@ -141,6 +145,18 @@ int tfem_reduce_scatter_linear(const void *integrand, int real_bytes, int64_t es
 int tfem_reduce_functional(const void *integrand, int real_bytes, int64_t es, int64_t qs,
                            const void *dx, int64_t n_elems, int n_quad, int n_inner, void *out,
                            void *stream);
+
+/* Gather map (HOST, once per mesh) and gather (DEVICE): the deterministic, atomic-free form
+ * of the scatter abstract_basis.py:87-91.  map: from the slots of tfem_csr_symbolic_fill,
+ * gptr_host (nnz+1) int64 and gsrc_host (n_elems*nn) int32 = for every CSR entry the
+ * entry-major indices of the local-block entries that add to it, in ascending (element,
+ * local entry) order -- the order a sequential index_put_(accumulate=True) adds them in.
+ * gather: vals[p] = sum_t local[gsrc[t]], t in [gptr[p], gptr[p+1]); local = the
+ * LOCAL-BLOCK output of tfem_tri_bilinear_csr / tfem_reduce_scatter_bilinear. */
+int tfem_csr_gather_map(const int32_t *slots_host, int64_t n_elems, int nn, int64_t nnz,
+                        int64_t *gptr_host, int32_t *gsrc_host);
+int tfem_csr_gather(const void *local, int real_bytes, const int64_t *gptr, const int32_t *gsrc,
+                    int64_t nnz, void *vals, void *stream);
 
 /* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */

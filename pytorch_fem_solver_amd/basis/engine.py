@@ -210,6 +210,8 @@ class AssemblyEngine:
         self._csr_host = None
         self._tiles = None
         self._rings = None
+        self._gather = None
+        self._slots_host = None
         #: "auto" (tile plan when the mesh allows it), "tiles" or "atomic"
         self.kernel = os.environ.get("TFEM_KERNEL", "auto")
 
@@ -248,6 +250,7 @@ class AssemblyEngine:
             conn = self._host_conn_dof.cpu().numpy()
             rowptr, colind, slots = symbolic_host(conn, self.n_dofs)
             self._csr_host = (rowptr, colind)
+            self._slots_host = slots
             dev = self.device
             self._csr = (
                 torch.from_numpy(rowptr).to(dev),
@@ -319,10 +322,38 @@ class AssemblyEngine:
                 raise NotImplementedError("the ring-plan kernel does not apply to this basis")
         return self._rings or None
 
+    def gather_map(self):
+        """(gptr int64, gsrc int32) on the compute device: for every CSR entry the local-block
+        entries that add to it, in the reference's accumulation order (tfem_csr_gather_map)."""
+        if self._gather is None:
+            self.csr_structure()
+            nn = self.n_local * self.n_local
+            nnz = int(self._csr_host[1].shape[0])
+            slots = np.ascontiguousarray(self._slots_host, dtype=np.int32)
+            gptr = np.zeros(nnz + 1, dtype=np.int64)
+            gsrc = np.zeros(max(slots.size, 1), dtype=np.int32)
+            _native.check(self.lib.tfem_csr_gather_map(
+                c_void_p(slots.ctypes.data), self.n_elems, nn, nnz,
+                c_void_p(gptr.ctypes.data), c_void_p(gsrc.ctypes.data)))
+            dev = self.device
+            self._gather = (torch.from_numpy(gptr).to(dev), torch.from_numpy(gsrc[: slots.size]).to(dev))
+        return self._gather
+
+    def _gather_local(self, local):
+        """CSR values from entry-major local blocks (n*n, E): one tfem_csr_gather launch."""
+        gptr, gsrc = self.gather_map()
+        nnz = int(gptr.shape[0]) - 1
+        vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self.lib.tfem_csr_gather(
+                _native.ptr(local), self.real_bytes, _native.ptr(gptr), _native.ptr(gsrc), nnz,
+                _native.ptr(vals), self._stream()))
+        return vals
+
     def kernel_name(self):
         """Name of the dominant numeric kernel (the one that writes K) as rocprofv3 reports it."""
         if self.poly_order != 1:
-            return "k_p2_bilinear_atomic"
+            return "k_p2_bilinear_atomic"  # element blocks (+ k_csr_gather unless TFEM_KERNEL=atomic)
         if self.ring_plan() is not None:
             return "k_p1_rings"
         return "k_p1_tiles_pipe" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
@@ -370,18 +401,24 @@ class AssemblyEngine:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
         _, colind, slots = self.csr_structure()
         nnz = int(colind.shape[0])
-        vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+        # P2, fractures, meshes without a plan: element blocks -> gather (no atomics, the
+        # reference's accumulation order); TFEM_KERNEL=atomic keeps the one-pass atomic scatter
+        two_pass = self.kernel != "atomic"
+        nn = self.n_local * self.n_local
+        out_len = nn * self.n_elems if two_pass else nnz
+        out = torch.empty(out_len, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_tri_bilinear_csr(
                     _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]), 4,
                     self.n_elems, self.coords_per_mesh, self.poly_order, self.quad_order,
-                    float(alpha), float(beta), _native.ptr(slots), _native.ptr(vals), nnz,
+                    float(alpha), float(beta), None if two_pass else _native.ptr(slots),
+                    _native.ptr(out), out_len,
                     _native.ptr(d["pinv"]), _native.ptr(d["fdet"]), self.n_fractures,
                     self.coords_per_mesh, self._stream(),
                 )
             )
-        return vals
+        return self._gather_local(out) if two_pass else out
 
     def _assemble_rings(self, alpha, beta, fq=None):
         """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass and,
@@ -483,15 +520,18 @@ class AssemblyEngine:
         dxf = dx.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
         _, colind, slots = self.csr_structure()
         nnz = int(colind.shape[0])
-        vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+        two_pass = self.kernel != "atomic"
+        out_len = n * n * self.n_elems if two_pass else nnz
+        out = torch.empty(out_len, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_reduce_scatter_bilinear(
                     _native.ptr(flat), self.real_bytes, es, qs, _native.ptr(dxf), self.n_elems,
-                    self.n_quad, n, _native.ptr(slots), _native.ptr(vals), nnz, self._stream(),
+                    self.n_quad, n, None if two_pass else _native.ptr(slots), _native.ptr(out),
+                    out_len, self._stream(),
                 )
             )
-        return vals
+        return self._gather_local(out) if two_pass else out
 
     def reduce_linear(self, integrand, dx):
         n = self.n_local

@@ -285,4 +285,31 @@ int tfem_csr_symbolic_fill(const void *conn_host, int idx_bytes, int64_t n_elems
                              rowptr_host, colind_host, slots_host);
 }
 
+int tfem_csr_gather_map(const int32_t *slots_host, int64_t n_elems, int nn, int64_t nnz,
+                        int64_t *gptr_host, int32_t *gsrc_host) {
+  if (n_elems < 0 || nn < 1 || nnz < 0 || !gptr_host || (n_elems > 0 && (!slots_host || !gsrc_host)))
+    return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  const int64_t n_entries = n_elems * nn;
+  if (n_entries >= (int64_t(1) << 31))
+    return tfem::fail(TFEM_ERR_INDEX_RANGE, "%lld local entries do not fit the int32 gather map",
+                      (long long)n_entries);
+  for (int64_t p = 0; p <= nnz; ++p) gptr_host[p] = 0;
+  for (int64_t t = 0; t < n_entries; ++t) {
+    const int32_t p = slots_host[t];
+    if (p < 0 || p >= nnz) return tfem::fail(TFEM_ERR_INDEX_RANGE, "slot %d outside [0, nnz)", p);
+    gptr_host[p + 1]++;
+  }
+  for (int64_t p = 0; p < nnz; ++p) gptr_host[p + 1] += gptr_host[p];
+  // element-major walk: every CSR entry lists its contributions in ascending (element, local
+  // entry) order, the order of a sequential index_put_(accumulate=True)
+  for (int64_t e = 0; e < n_elems; ++e)
+    for (int k = 0; k < nn; ++k) {
+      const int32_t p = slots_host[e * nn + k];
+      gsrc_host[gptr_host[p]++] = int32_t(int64_t(k) * n_elems + e);  // entry-major local index
+    }
+  for (int64_t p = nnz; p > 0; --p) gptr_host[p] = gptr_host[p - 1];
+  gptr_host[0] = 0;
+  return TFEM_OK;
+}
+
 }  // extern "C"

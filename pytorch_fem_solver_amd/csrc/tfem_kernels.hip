@@ -163,6 +163,11 @@ __global__ __launch_bounds__(kBlock) void k_p1_bilinear_atomic(const TriArgs<T, 
       loc[j][i] = acc;  // bitwise symmetric: same products, same order
     }
   }
+  if (!a.slots) {  // local blocks, entry-major (9, n_elems): lanes store contiguously
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.vals[int64_t(k) * a.n_elems + e] = loc[k / 3][k % 3];
+    return;
+  }
   const int32_t *s = a.slots + 9 * e;
 #pragma unroll
   for (int k = 0; k < 9; ++k) atomic_add(a.vals + s[k], loc[k / 3][k % 3]);
@@ -208,6 +213,18 @@ __global__ __launch_bounds__(kBlock) void k_p2_bilinear_atomic(const TriArgs<T, 
         acc[k] = acc[k] + term * dxq;
       }
     }
+  }
+  if (!a.slots) {  // local blocks, entry-major (36, n_elems)
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = i; j < 6; ++j, ++k) {
+        a.vals[int64_t(6 * i + j) * a.n_elems + e] = acc[k];
+        if (j != i) a.vals[int64_t(6 * j + i) * a.n_elems + e] = acc[k];
+      }
+    }
+    return;
   }
   const int32_t *s = a.slots + 36 * e;
   int k = 0;
@@ -324,7 +341,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce_bilinear(const T *integrand, 
   const T *w = dx + e * nq;
   T acc = T(0);
   for (int q = 0; q < nq; ++q) acc = acc + p[q * qs] * w[q];
-  atomic_add(vals + slots[idx], acc);
+  if (!slots)
+    vals[int64_t(k) * (n_entries / nn) + e] = acc;  // local blocks, entry-major (nn, n_elems)
+  else
+    atomic_add(vals + slots[idx], acc);
 }
 
 template <typename T, typename I>
@@ -444,12 +464,14 @@ static int run_bilinear(const void *coords, const void *conn_geo, int64_t n_elem
   if (int st = setup_args(a, coords, conn_geo, n_elems, n_verts, quad_order, fr, tables))
     return st;
   if (nnz > 0 && !vals) return fail(TFEM_ERR_INVALID_ARGUMENT, "vals is NULL");
-  if (n_elems > 0 && !slots) return fail(TFEM_ERR_INVALID_ARGUMENT, "slots is NULL");
+  const int nn = poly_order == 2 ? 36 : 9;
+  if (!slots && nnz != nn * n_elems)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "local-block mode: vals must hold %d * n_elems entries", nn);
   a.alpha = T(alpha);
   a.beta = T(beta);
   a.slots = slots;
   a.vals = static_cast<T *>(vals);
-  if (nnz > 0) TFEM_HIP_CHECK(hipMemsetAsync(vals, 0, size_t(nnz) * sizeof(T), stream));
+  if (slots && nnz > 0) TFEM_HIP_CHECK(hipMemsetAsync(vals, 0, size_t(nnz) * sizeof(T), stream));
   if (n_elems == 0) return TFEM_OK;
   const dim3 grid(blocks_for(n_elems)), block(kBlock);
   if (poly_order == 1) {
@@ -560,6 +582,19 @@ using namespace tfem;
        ? (idx_bytes == 4 ? FN<double, int32_t>(__VA_ARGS__) : FN<double, int64_t>(__VA_ARGS__)) \
        : (idx_bytes == 4 ? FN<float, int32_t>(__VA_ARGS__) : FN<float, int64_t>(__VA_ARGS__)))
 
+// CSR values from entry-major local blocks through the gather map (tfem_csr_gather_map): one
+// lane per CSR entry sums its contributions in ascending element order -- the order of the
+// reference's sequential index_put_(accumulate=True) -- no atomics, bitwise reproducible.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_csr_gather(const T *local, const int64_t *gptr,
+                                                        const int32_t *gsrc, int64_t nnz, T *vals) {
+  const int64_t p = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= nnz) return;
+  T acc = T(0);
+  for (int64_t t = gptr[p]; t < gptr[p + 1]; ++t) acc = acc + local[gsrc[t]];
+  vals[p] = acc;
+}
+
 // Interface exchange of the element-range sharding (parallel.py): entries of the local CSR
 // values / local vector that belong to DoFs shared with another rank are copied into the
 // packed buffer the ranks all-reduce (pack) and back (unpack).  One launch each.
@@ -641,11 +676,12 @@ int tfem_reduce_scatter_bilinear(const void *integrand, int real_bytes, int64_t 
   if (int st = check_common(real_bytes, 4, n_elems)) return st;
   if (n_quad < 1 || n_local < 1 || nnz < 0)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad n_quad / n_local / nnz");
-  if (n_elems > 0 && (!integrand || !dx || !slots))
-    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL input");
+  if (n_elems > 0 && (!integrand || !dx)) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL input");
   if (nnz > 0 && !vals) return fail(TFEM_ERR_INVALID_ARGUMENT, "vals is NULL");
+  if (!slots && nnz != int64_t(n_local) * n_local * n_elems)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "local-block mode: vals must hold n_local^2 * n_elems entries");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (nnz > 0) TFEM_HIP_CHECK(hipMemsetAsync(vals, 0, size_t(nnz) * size_t(real_bytes), s));
+  if (slots && nnz > 0) TFEM_HIP_CHECK(hipMemsetAsync(vals, 0, size_t(nnz) * size_t(real_bytes), s));
   if (n_elems == 0) return TFEM_OK;
   const int nn = n_local * n_local;
   const int64_t entries = n_elems * nn;
@@ -718,6 +754,23 @@ int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *
     hipLaunchKernelGGL(k_csr_to_dense<float>, dim3(blocks_for(n_dofs)), dim3(kBlock), 0, s,
                        rowptr, colind, static_cast<const float *>(vals), n_dofs,
                        static_cast<float *>(dense));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_csr_gather(const void *local, int real_bytes, const int64_t *gptr, const int32_t *gsrc,
+                    int64_t nnz, void *vals, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (nnz < 0 || (nnz > 0 && (!local || !gptr || !gsrc || !vals)))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (nnz == 0) return TFEM_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_csr_gather<double>, dim3(blocks_for(nnz)), dim3(kBlock), 0, s,
+                       static_cast<const double *>(local), gptr, gsrc, nnz, static_cast<double *>(vals));
+  else
+    hipLaunchKernelGGL(k_csr_gather<float>, dim3(blocks_for(nnz)), dim3(kBlock), 0, s,
+                       static_cast<const float *>(local), gptr, gsrc, nnz, static_cast<float *>(vals));
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

@@ -74,6 +74,46 @@ def test_symbolic_phase_against_oracle(kind):
     assert np.array_equal(slots, s2.reshape(-1))
 
 
+@pytest.mark.parametrize("kind", ["p1", "p2"])
+def test_gather_map_lists_every_contribution_in_reference_order(kind):
+    """tfem_csr_gather_map: every local-block entry appears exactly once, under the CSR entry
+    its slot names, and the contributions of an entry are in ascending (element, local entry)
+    order -- the order of a sequential index_put_(accumulate=True)."""
+    import ctypes
+
+    from pytorch_fem_solver_amd import _native, dofs, meshgen
+    from pytorch_fem_solver_amd.basis.engine import symbolic_host
+
+    mesh = meshgen.delaunay_square(300, 7)
+    conn, n = mesh["triangles"], mesh["vertices"].shape[0]
+    if kind == "p2":
+        conn, xy, _ = dofs.p2_dofs_numpy(mesh["vertices"], mesh["triangles"], mesh["edges"],
+                                         mesh["edge_markers"], mesh["vertex_markers"])
+        n = xy.shape[0]
+    rowptr, colind, slots = symbolic_host(conn, n)
+    ne, nl = conn.shape
+    nn, nnz = nl * nl, colind.shape[0]
+    gptr = np.zeros(nnz + 1, dtype=np.int64)
+    gsrc = np.zeros(ne * nn, dtype=np.int32)
+    lib = _native.load()
+    _native.check(lib.tfem_csr_gather_map(ctypes.c_void_p(slots.ctypes.data), ne, nn, nnz,
+                                          ctypes.c_void_p(gptr.ctypes.data), ctypes.c_void_p(gsrc.ctypes.data)))
+    assert gptr[0] == 0 and gptr[-1] == ne * nn and np.all(np.diff(gptr) >= 1)
+    assert np.array_equal(np.sort(gsrc), np.arange(ne * nn))
+    k, e = np.divmod(gsrc.astype(np.int64), ne)  # entry-major local index = k * E + e
+    owner = np.repeat(np.arange(nnz), np.diff(gptr))
+    assert np.array_equal(slots.reshape(ne, nn)[e, k], owner)
+    flat = e * nn + k
+    same = owner[1:] == owner[:-1]
+    assert np.all(flat[1:][same] > flat[:-1][same])
+    # the sums through the map equal the oracle's scatter
+    rng = np.random.default_rng(0)
+    local = rng.standard_normal((ne, nl, nl))
+    want = orc.assemble_csr_values(local, slots.reshape(ne, nl, nl), nnz)
+    got = np.add.reduceat(local.reshape(ne, nn).T.reshape(-1)[gsrc], gptr[:-1])
+    assert scaled_error(got, want) <= 1e-14
+
+
 def test_symbolic_phase_empty_mesh():
     from pytorch_fem_solver_amd.basis.engine import symbolic_host
 

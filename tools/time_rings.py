@@ -96,15 +96,23 @@ if "rings" in args.kernels:
     fn = _native.load().tfem_p1_rings_debug
     fn.restype = ctypes.c_int
     names = ["A loads", "B rows", "stage", "vmcnt0", "park", "stores", "barrier"]
+    import math
+    pts = eng.geometry()[2]
+    fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
+    del pts
+    fout = torch.empty(eng.n_dofs)
     print("cycles per tile per wave:   " + " ".join(f"{n:>8s}" for n in names) + "    total")
-    for label, extra in (("full", 0), ("no stores", 1), ("no arithmetic", 2), ("no gather", 4),
-                         ("no stores+arith", 3)):
-        for per_cu in (0, 2):
+    for label, extra, load in (("full", 0, False), ("no stores", 1, False), ("no arithmetic", 2, False),
+                               ("no gather", 4, False), ("no stores+arith", 3, False),
+                               ("K + f full", 0, True), ("K + f no stores", 1, True), ("K + f no arith", 2, True)):
+        for per_cu in (0, 2) if not load else (0, 1):
             stamps.zero_()
             _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
                              _native.ptr(rings["blob"]), ctypes.c_void_p(rings["layout"].ctypes.data),
                              _native.ptr(vals), ctypes.c_int64(nnz), _native.current_stream(eng.device),
-                             256 | extra, per_cu, _native.ptr(stamps), None, ctypes.c_int64(0), None))
+                             256 | extra, per_cu, _native.ptr(stamps),
+                             _native.ptr(fq) if load else None, ctypes.c_int64(eng.n_elems if load else 0),
+                             _native.ptr(fout) if load else None))
             torch.cuda.synchronize()
             t = stamps.cpu().numpy().reshape(-1, 8)
             t = t[t[:, 7] > 0]
