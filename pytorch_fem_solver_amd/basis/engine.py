@@ -314,13 +314,30 @@ class AssemblyEngine:
                 except NotImplementedError:
                     plan = None
                 if plan is not None:
+                    # rows per output run (group of rows contiguous in the CSR array): the ring
+                    # kernel streams a wave's rows out run by run, so a numbering without
+                    # locality (about one run per row) is served better by the tile kernel
+                    step = np.diff(plan["rowstart"].astype(np.int64))
+                    n_runs = 1 + int(np.count_nonzero((step <= 0) | (step > 16)))
                     self._rings = {
                         "blob": torch.from_numpy(plan["blob"]).to(self.device),
                         "layout": plan["layout"],
+                        "chunked": plan["chunked"],
+                        "rows_per_run": plan["rowstart"].size / n_runs,
                     }
             if self._rings is False and self.kernel == "rings":
                 raise NotImplementedError("the ring-plan kernel does not apply to this basis")
         return self._rings or None
+
+    def _use_rings(self):
+        """Ring kernel when its plan exists and the output runs are long enough (always with
+        consecutive-vertex tiles), or when nothing else applies / it was asked for."""
+        rings = self.ring_plan()
+        if rings is None:
+            return False
+        if self.kernel == "rings" or rings["chunked"] or rings["rows_per_run"] >= 8.0:
+            return True
+        return self.tile_plan() is None
 
     def gather_map(self):
         """(gptr int64, gsrc int32) on the compute device: for every CSR entry the local-block
@@ -354,7 +371,7 @@ class AssemblyEngine:
         """Name of the dominant numeric kernel (the one that writes K) as rocprofv3 reports it."""
         if self.poly_order != 1:
             return "k_p2_bilinear_atomic"  # element blocks (+ k_csr_gather unless TFEM_KERNEL=atomic)
-        if self.ring_plan() is not None:
+        if self._use_rings():
             return "k_p1_rings"
         return "k_p1_tiles_pipe" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
 
@@ -395,7 +412,7 @@ class AssemblyEngine:
     def bilinear(self, alpha: float, beta: float):
         """CSR values of alpha*stiffness + beta*mass (fused kernel)."""
         d = self._inputs()
-        if self.ring_plan() is not None:
+        if self._use_rings():
             return self._assemble_rings(alpha, beta)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
@@ -470,7 +487,7 @@ class AssemblyEngine:
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
         values fq (E, Q): one fused launch on the ring and tile paths, two launches
         otherwise."""
-        if self.ring_plan() is not None:
+        if self._use_rings():
             return self._assemble_rings(alpha, beta, fq)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)

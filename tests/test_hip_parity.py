@@ -370,18 +370,28 @@ def test_ring_kernel_mixed_orientation_and_open_fans(dtype, form):
         assert scaled_error(got.cpu().double(), want) <= tol, (name, form)
 
 
+@pytest.mark.parametrize("kernel", ["rings", "tiles", "auto_morton"])
 @pytest.mark.parametrize("order", [1, 2, 3, 4])
-def test_fused_system_launch_matches_separate_forms(order):
-    """engine.assemble_system = one tile-kernel launch for K and f (bench.py's step)."""
+def test_fused_system_launch_matches_separate_forms(order, kernel):
+    """engine.assemble_system = ONE launch for K and f (bench.py's step): the ring kernel (Delaunay
+    mesh: 15-slot records; native numbering = Z-order tiles with one output run per row, Morton
+    numbering = consecutive-vertex tiles, the plan the engine picks by itself) and the tile
+    kernel."""
     from pytorch_fem_solver_amd import meshgen
 
     mesh_np = meshgen.delaunay_square(6000, 11)
+    if kernel == "auto_morton":
+        mesh_np = meshgen.permute_mesh(mesh_np, vertex_order=meshgen.morton_order(mesh_np["vertices"]))
     nv = mesh_np["vertices"].shape[0]
     basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, order))
+    if kernel != "auto_morton":
+        basis._engine.kernel = kernel
     x, y = torch.split(basis.integration_points, 1, dim=-1)
     fq = rhs(x, y).reshape(-1, basis._engine.n_quad)
     vals, f = basis._engine.assemble_system(1.0, 1.0, fq)
-    assert basis._engine.kernel_name() == "k_p1_rings"
+    assert basis._engine.kernel_name() == ("k_p1_tiles_pipe" if kernel == "tiles" else "k_p1_rings")
+    if kernel == "auto_morton":
+        assert basis._engine.ring_plan()["chunked"]
     local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "stiffness_mass")
     _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
     assert scaled_error(vals.cpu(), orc.assemble_csr_values(local, slots, colind.shape[0])) <= TOL
@@ -393,6 +403,17 @@ def test_fused_system_launch_matches_separate_forms(order):
     basis2 = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, order))
     basis2._engine.kernel = "atomic"
     assert scaled_error(basis2._engine.load(fq).cpu(), f.cpu()) <= 1e-13
+
+
+def test_engine_picks_the_tile_kernel_for_a_numbering_without_locality():
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.delaunay_square(6000, 11)  # scipy's point order: about one output run per row
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+    assert basis._engine.kernel_name() == "k_p1_tiles_pipe"
+    assert basis._engine.ring_plan()["rows_per_run"] < 8.0
+    basis = tf().Basis(tf().MeshTri(meshgen.unit_square(50, 0.25, 0)), tf().ElementTri(1, 3))
+    assert basis._engine.kernel_name() == "k_p1_rings" and basis._engine.ring_plan()["chunked"]
 
 
 def test_edge_cases_empty_and_single_element():
