@@ -263,6 +263,33 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
                            const void *fq, int64_t n_elems, void *fout, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * P2 row plan (HOST, once per mesh) + P2 row kernels (DEVICE): alpha * stiffness +
+ * beta * mass for the quadratic element in owner-computes ROW form (one lane per CSR
+ * row of a vertex DoF or of an edge DoF, no atomics).  Same operation as
+ * tfem_tri_bilinear_csr with poly_order = 2 (abstract_basis.py:74-93, element_tri.py:43-70);
+ * requires DoFs numbered "vertices, then edges" with the local edge order (v0,v1), (v1,v2),
+ * (v2,v0) (conn_dof (n_elems, 6), vertex DoF id = vertex id), at most 7 neighbours per
+ * vertex and a numbering with locality; otherwise create returns TFEM_ERR_UNSUPPORTED and
+ * the caller uses the local-block + gather path.
+ *   sizes : layout[24]: [0] vertex-row tiles [1] edge-row tiles [2] n_verts [3] n_edges
+ *           [4] max local vertices of a vertex tile [5] of an edge tile [6] max halo of a
+ *           vertex tile [7],[8] local vertices listed for vertex / edge tiles
+ *           [10..15] byte offsets of desc, rows, vert_gid of the vertex tiles and of the edge
+ *           tiles in the packed plan [16] bytes of the packed plan
+ *   pack  : record and descriptor layout: csrc/tfem_p2rows_host.cpp
+ * ------------------------------------------------------------------------- */
+int tfem_p2_plan_create(const int32_t *conn_dof_host, int64_t n_elems, int64_t n_verts,
+                        int64_t n_dofs, const double *coords_host, const int64_t *rowptr_host,
+                        const int32_t *colind_host, void **plan_out);
+int tfem_p2_plan_sizes(const void *plan, int64_t layout[24]);
+int tfem_p2_plan_pack(const void *plan, void *blob_host);
+void tfem_p2_plan_destroy(void *plan);
+/* vals (nnz): every entry written exactly once (two launches: vertex rows, edge rows). */
+int tfem_p2_assemble_rows(const void *coords, int real_bytes, int quad_order, double alpha,
+                          double beta, const void *plan_device, const int64_t *plan_layout_host,
+                          void *vals, int64_t nnz, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Interface exchange of the multi-GPU sharding (DEVICE; the path shards by element
  * range, DoFs on an inter-rank interface are summed with one all-reduce of a packed
  * buffer: SURVEY 8(e); the reference is single-process).  pack: buf (nbuf) is zeroed,

@@ -88,6 +88,16 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
          c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "tfem_p2_plan_create": (
+        c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "tfem_p2_plan_sizes": (c_int, [c_void_p, c_void_p]),
+    "tfem_p2_plan_pack": (c_int, [c_void_p, c_void_p]),
+    "tfem_p2_plan_destroy": (None, [c_void_p]),
+    "tfem_p2_assemble_rows": (
+        c_int,
+        [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    ),
     "tfem_csr_gather_map": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "tfem_csr_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tfem_interface_pack": (

@@ -180,6 +180,42 @@ def unpack_ring_plan(blob, layout):
     }
 
 
+def p2_plan_host(conn_dof, n_verts, n_dofs, coords, rowptr, colind):
+    """Build the P2 row plan on the host (tfem_p2_plan_*).  Raises NotImplementedError when
+    the mesh does not fit it (DoF layout, vertices with more than 7 neighbours, numbering
+    without locality)."""
+    lib = _native.load()
+    conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32)).reshape(-1, 6)
+    coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
+    rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
+    colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
+    handle = c_void_p()
+    _native.check(
+        lib.tfem_p2_plan_create(
+            c_void_p(conn.ctypes.data), conn.shape[0], int(n_verts), int(n_dofs),
+            c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
+            c_void_p(colind.ctypes.data), ctypes.byref(handle),
+        )
+    )
+    try:
+        layout = np.zeros(24, dtype=np.int64)
+        _native.check(lib.tfem_p2_plan_sizes(handle, c_void_p(layout.ctypes.data)))
+        blob = np.zeros(int(layout[16]), dtype=np.uint8)
+        _native.check(lib.tfem_p2_plan_pack(handle, c_void_p(blob.ctypes.data)))
+    finally:
+        lib.tfem_p2_plan_destroy(handle)
+    z = [int(x) for x in layout]
+    view = lambda i, dtype, count: np.frombuffer(blob, dtype=dtype, count=count, offset=z[10 + i])  # noqa: E731
+    return {
+        "blob": blob,
+        "layout": np.ascontiguousarray(layout, dtype=np.int64),
+        "vertex": {"desc": view(0, np.int32, 16 * z[0]), "rows": view(1, np.uint32, 8 * z[2]),
+                   "vert_gid": view(2, np.int32, z[7])},
+        "edge": {"desc": view(3, np.int32, 16 * z[1]), "rows": view(4, np.uint32, 4 * z[3]),
+                 "vert_gid": view(5, np.int32, z[8])},
+    }
+
+
 class AssemblyEngine:
     def __init__(self, coords, conn_geo, conn_dof, n_dofs, poly_order, quad_order, fracture=None):
         """coords (N_v,2) or (F,N_v,2); conn_geo (N_T,3) or (F,N_T,3) vertex ids (per mesh);
@@ -212,6 +248,7 @@ class AssemblyEngine:
         self._rings = None
         self._gather = None
         self._slots_host = None
+        self._p2rows = None
         #: "auto" (tile plan when the mesh allows it), "tiles" or "atomic"
         self.kernel = os.environ.get("TFEM_KERNEL", "auto")
 
@@ -329,6 +366,30 @@ class AssemblyEngine:
                 raise NotImplementedError("the ring-plan kernel does not apply to this basis")
         return self._rings or None
 
+    def p2_plan(self):
+        """Device copy of the P2 row plan, or None when this basis cannot use it."""
+        if self._p2rows is None:
+            self._p2rows = False
+            if (self.kernel in ("auto", "rows") and self.poly_order == 2 and self.n_fractures == 0
+                    and self._host_conn_geo.dim() == 2):
+                self.csr_structure()
+                rowptr, colind = self._csr_host
+                try:
+                    plan = p2_plan_host(
+                        self._host_conn_dof.cpu().numpy(), self.coords_per_mesh, self.n_dofs,
+                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                    )
+                except NotImplementedError:
+                    plan = None
+                if plan is not None:
+                    self._p2rows = {
+                        "blob": torch.from_numpy(plan["blob"]).to(self.device),
+                        "layout": plan["layout"],
+                    }
+            if self._p2rows is False and self.kernel == "rows":
+                raise NotImplementedError("the P2 row kernels do not apply to this basis")
+        return self._p2rows or None
+
     def _use_rings(self):
         """Ring kernel when its plan exists and the output runs are long enough (always with
         consecutive-vertex tiles), or when nothing else applies / it was asked for."""
@@ -370,6 +431,8 @@ class AssemblyEngine:
     def kernel_name(self):
         """Name of the dominant numeric kernel (the one that writes K) as rocprofv3 reports it."""
         if self.poly_order != 1:
+            if self.p2_plan() is not None:
+                return "k_p2_rows"
             return "k_p2_bilinear_atomic"  # element blocks (+ k_csr_gather unless TFEM_KERNEL=atomic)
         if self._use_rings():
             return "k_p1_rings"
@@ -418,6 +481,18 @@ class AssemblyEngine:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
         _, colind, slots = self.csr_structure()
         nnz = int(colind.shape[0])
+        if self.p2_plan() is not None:
+            rows = self.p2_plan()
+            vals = torch.empty(nnz, dtype=self.dtype, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(
+                    self.lib.tfem_p2_assemble_rows(
+                        _native.ptr(d["coords"]), self.real_bytes, self.quad_order, float(alpha),
+                        float(beta), _native.ptr(rows["blob"]), c_void_p(rows["layout"].ctypes.data),
+                        _native.ptr(vals), nnz, self._stream(),
+                    )
+                )
+            return vals
         # P2, fractures, meshes without a plan: element blocks -> gather (no atomics, the
         # reference's accumulation order); TFEM_KERNEL=atomic keeps the one-pass atomic scatter
         two_pass = self.kernel != "atomic"

@@ -1,0 +1,367 @@
+// P2 (quadratic) alpha * stiffness + beta * mass over a P2 row plan (tfem_p2rows_host.cpp):
+// owner-computes ROW form, one lane per CSR row, no atomics -- the P2 counterpart of
+// tfem_rings.hip.
+//
+// On an affine triangle with frame (p0, p1, p2), e1 = p1 - p0, e2 = p2 - p0, det = e1 x e2
+// (signed, element_tri.py:139) the physical gradient of a P2 shape function is
+// rgrad_a(q) @ J^-1 = rg_a0 grad(l_1) + rg_a1 grad(l_2) (element_tri.py:43-70), so the element
+// block (abstract_basis.py:83) is a CONSTANT linear map of three numbers:
+//     K_ab = A_ab G11 + B_ab G12 + D_ab G22 + (beta M_ab) det
+//     G11 = |e2|^2 / det, G12 = -(e1.e2) / det, G22 = |e1|^2 / det
+//     A_ab = sum_q w_q/2 rg_a0 rg_b0, B_ab = sum_q w_q/2 (rg_a0 rg_b1 + rg_a1 rg_b0),
+//     D_ab = sum_q w_q/2 rg_a1 rg_b1, M_ab = sum_q w_q/2 phi_a phi_b
+// with the tables formed once on the host in the real type from the reference's own shape
+// function tables.  A row needs one row of that block per incident triangle: row 0 (the vertex
+// at p0) for a vertex DoF, row 3 (the edge (p0, p1)) for an edge DoF -- the frame is rotated so
+// that the row's DoF sits there; the shape functions and the quadrature rules are symmetric
+// under that relabelling, so this is the stored element's block up to rounding (parity is
+// asserted at 1e-12 against the oracle).
+//
+// One tile per 256-lane workgroup: coordinates of the tile's vertices -> LDS, one barrier, then
+// every lane walks its row, stages the entries in CSR order in its wave's LDS stage and the
+// wave streams them out with 16-byte stores (a wave's rows are consecutive DoFs: one
+// contiguous piece of the CSR array whose offset is in the descriptor).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "tfem_common.hpp"
+#include "tfem_rowkit.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace tfem {
+
+constexpr int kP2Block = 256;
+constexpr int kP2Waves = kP2Block / 64;
+constexpr int kP2VertexRowMax = 22;  // 1 + 3 * 7
+constexpr int kP2EdgeRowMax = 9;
+
+template <typename T>
+struct P2RowArgs {
+  const T *coords;
+  const unsigned char *plan;
+  T *vals;
+  unsigned coords_bytes, plan_bytes, vals_bytes;
+  unsigned off_desc, off_rows, off_gid;
+  int n_tiles;
+  int lds_vert;
+  // row 0 (vertex kinds) or row 3 (edge kind) of the constant maps, alpha / beta folded in
+  T ca[6], cb[6], cd[6], cm[6];
+};
+
+// entries r[0..6) of one row of the element block in the frame whose edge vectors are e1, e2
+template <typename T, bool MASS>
+__device__ __forceinline__ void p2_block_row(const P2RowArgs<T> &a, T q1, T q2, T p, T cross,
+                                             uint32_t flag, T (&r)[6]) {
+  // flag: 0 no triangle (all zero), 1 frame = (e1, e2) as given, 2 frame = (e2, e1)
+  const T c = flag_weight<T>(T(1), flag) * fast_rcp<T>(flag ? cross : T(1));  // 1 / det or 0
+  const T g11 = c * (flag == 2u ? q1 : q2);
+  const T g12 = -(c * p);
+  const T g22 = c * (flag == 2u ? q2 : q1);
+  const T det = flag_weight<T>(T(1), flag) * cross;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    T v = a.ca[m] * g11 + a.cb[m] * g12 + a.cd[m] * g22;
+    if (MASS) v = v + a.cm[m] * det;
+    r[m] = v;
+  }
+}
+
+// The wave's stage -> global memory: the wave's rows are consecutive DoFs, so stage index +
+// delta = CSR index.  Lane j of step u takes entries 128 u + 2 j and the next one.
+template <typename T, int MAXLEN>
+__device__ __forceinline__ void p2_store(const T *stage, int total, int delta, ring_rsrc_t r_vals) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kSteps = (64 * MAXLEN + 127) / 128;
+#pragma unroll
+  for (int u = 0; u < kSteps; ++u) {
+    if (128 * u < total) {  // wave-uniform
+      const int s0 = 128 * u + 2 * lane;
+      const T v0 = stage[s0], v1 = stage[s0 + 1];
+      const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
+      if (128 * (u + 1) <= total || s0 + 1 < total) {
+        if constexpr (sizeof(T) == 8) {
+          const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b64(
+              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+        }
+      } else if (s0 < total) {
+        if constexpr (sizeof(T) == 8)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+      }
+    }
+  }
+}
+
+// KIND 0: vertex rows, KIND 1: edge rows
+template <typename T, int KIND, bool MASS>
+__global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
+  constexpr int kMaxLen = KIND == 0 ? kP2VertexRowMax : kP2EdgeRowMax;
+  constexpr int kStageEntries = 64 * kMaxLen + 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p2_smem[];
+  T *xy = reinterpret_cast<T *>(p2_smem);  // [2 * lds_vert]
+  T *stage = xy + 2 * a.lds_vert;          // [waves][kStageEntries]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = (a.n_tiles + 7) / 8;
+  const int tile = int(blockIdx.x & 7) * per + int(blockIdx.x >> 3);
+  if (tile >= a.n_tiles || int(blockIdx.x >> 3) >= per) return;
+  ring_const_i32 d = (ring_const_i32)(uintptr_t)(a.plan + a.off_desc + 64u * unsigned(tile));
+  const int vert_off = d[0], n_vert = d[1], row_off = d[2], n_own = d[7];
+  const int row0 = d[3 + wave], row1 = d[4 + wave], rs0 = d[12 + wave];
+  const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
+  const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
+  const ring_rsrc_t r_vals = ring_rsrc(a.vals, a.vals_bytes);
+  const int my_row = row0 + lane;
+  const bool has_row = my_row < row1;
+  constexpr unsigned kNone = 0x3FFFFFFu;
+  constexpr int kWords = KIND == 0 ? 8 : 4;
+  uint32_t w[kWords];
+  {
+    const unsigned byte = a.off_rows + (has_row ? unsigned(row_off + my_row) : kNone) * unsigned(4 * kWords);
+    const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, byte, 0, 0);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+    if constexpr (KIND == 0) {
+      const ru32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_plan, byte + 16u, 0, 0);
+      w[4] = u.x;
+      w[5] = u.y;
+      w[6] = u.z;
+      w[7] = u.w;
+    }
+  }
+  // coordinates of the tile's vertices -> LDS.  Vertex tiles: the lane's own vertex is
+  // gid0 + lane (consecutive ids, nothing read), the halo comes from the id list; edge tiles:
+  // every vertex from the list.
+  if (KIND == 0) {
+    if (has_row) {
+      T x, y;
+      ring_load_xy<T>(r_coords, unsigned(d[8 + wave] + lane), x, y);
+      xy[2 * my_row] = x;
+      xy[2 * my_row + 1] = y;
+    }
+    for (int l = n_own + tid; l < n_vert; l += kP2Block) {
+      const unsigned g = __builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_gid + unsigned(vert_off + l) * 4u, 0, 0);
+      T x, y;
+      ring_load_xy<T>(r_coords, g, x, y);
+      xy[2 * l] = x;
+      xy[2 * l + 1] = y;
+    }
+  } else {
+    for (int l = tid; l < n_vert; l += kP2Block) {
+      const unsigned g = __builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_gid + unsigned(vert_off + l) * 4u, 0, 0);
+      T x, y;
+      ring_load_xy<T>(r_coords, g, x, y);
+      xy[2 * l] = x;
+      xy[2 * l + 1] = y;
+    }
+  }
+  __syncthreads();
+
+  T *my_stage = stage + wave * kStageEntries;
+  constexpr int kSpare = 64 * kMaxLen;
+  int len, pre;
+  if constexpr (KIND == 0) {
+    // ---- vertex row: the fan, as in tfem_rings.hip ----------------------------------------
+    const int k = int((w[2] >> 24) & 7u);
+    auto id = [&](int i) { return (w[i / 3] >> (10 * (i % 3))) & 0x3FFu; };
+    auto flag_of = [&](int i) { return (w[2] >> (10 + 2 * i)) & 3u; };
+    auto field = [&](int f) { return int((w[3 + f / 6] >> (5 * (f % 6))) & 31u); };
+    T xv, yv, px, py;
+    lds_xy(xy, unsigned(has_row ? my_row : 0), xv, yv);
+    const uint32_t id0 = id(0);
+    lds_xy(xy, id0, px, py);
+    T ecx = px - xv, ecy = py - yv;
+    T qc = ecx * ecx + ecy * ecy;
+    T diag = T(0), vcol[8], ecol[8], ocol[7];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vcol[i] = ecol[i] = T(0);
+    int n_tri = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const uint32_t idn = (i + 1 < 7 && i + 1 != k) ? id(i + 1 < 7 ? i + 1 : 0) : id0;
+      lds_xy(xy, idn, px, py);
+      const T enx = px - xv, eny = py - yv;
+      const T qn = enx * enx + eny * eny;
+      const T p = ecx * enx + ecy * eny;
+      const T cross = ecx * eny - ecy * enx;
+      const uint32_t flag = flag_of(i);  // 0 for every slot i >= k
+      n_tri += flag ? 1 : 0;
+      T r[6];
+      p2_block_row<T, MASS>(a, qc, qn, p, cross, flag, r);
+      // r: v, p1, p2, edge (v,p1), edge (p1,p2), edge (p2,v); (p1, p2) = (n_i, n_next) for
+      // flag 1 and (n_next, n_i) for flag 2
+      const bool fwd = flag != 2u;
+      diag = diag + r[0];
+      vcol[i] = vcol[i] + (fwd ? r[1] : r[2]);
+      vcol[i + 1] = vcol[i + 1] + (fwd ? r[2] : r[1]);
+      ecol[i] = ecol[i] + (fwd ? r[3] : r[5]);
+      ecol[i + 1] = ecol[i + 1] + (fwd ? r[5] : r[3]);
+      ocol[i] = r[4];
+      ecx = enx;
+      ecy = eny;
+      qc = qn;
+    }
+    // what the closing triangle left in slot k belongs to slot 0
+    T wv = vcol[1], we = ecol[1];
+#pragma unroll
+    for (int j = 2; j <= 7; ++j) {
+      wv = k == j ? vcol[j] : wv;
+      we = k == j ? ecol[j] : we;
+    }
+    vcol[0] = vcol[0] + wv;
+    ecol[0] = ecol[0] + we;
+    len = k > 0 ? 1 + 2 * k + n_tri : 0;
+    const int incl = wave_inclusive_scan(len);
+    pre = incl - len;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      my_stage[i < k ? pre + field(i) : kSpare] = vcol[i];
+      my_stage[i < k ? pre + field(7 + i) : kSpare] = ecol[i];
+      my_stage[(i < k && flag_of(i)) ? pre + field(14 + i) : kSpare] = ocol[i];
+    }
+    my_stage[k > 0 ? pre + int(w[2] >> 27) : kSpare] = diag;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    __builtin_amdgcn_wave_barrier();
+    p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+  } else {
+    // ---- edge row: one or two triangles, each in its own stored frame ------------------------
+    const bool has2 = (w[1] >> 10) & 1u;
+    const bool rev = (w[1] >> 11) & 1u;
+    T ax, ay, bx, by, cx, cy, dx, dy;
+    lds_xy(xy, w[0] & 0x3FFu, ax, ay);
+    lds_xy(xy, (w[0] >> 10) & 0x3FFu, bx, by);
+    lds_xy(xy, (w[0] >> 20) & 0x3FFu, cx, cy);
+    lds_xy(xy, w[1] & 0x3FFu, dx, dy);
+    T r[6], s[6];
+    {
+      const T e1x = bx - ax, e1y = by - ay, e2x = cx - ax, e2y = cy - ay;
+      p2_block_row<T, MASS>(a, e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y, e1x * e2x + e1y * e2y,
+                            e1x * e2y - e1y * e2x, has_row ? 1u : 0u, r);
+    }
+    {
+      // frame (a2, b2, d) = (b, a, d) when rev, (a, b, d) otherwise
+      const T ox = rev ? bx : ax, oy = rev ? by : ay;
+      const T tx = rev ? ax : bx, ty = rev ? ay : by;
+      const T e1x = tx - ox, e1y = ty - oy, e2x = dx - ox, e2y = dy - oy;
+      p2_block_row<T, MASS>(a, e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y, e1x * e2x + e1y * e2y,
+                            e1x * e2y - e1y * e2x, (has_row && has2) ? 1u : 0u, s);
+    }
+    len = has_row ? (has2 ? 9 : 6) : 0;
+    const int incl = wave_inclusive_scan(len);
+    pre = incl - len;
+    auto pos = [&](int f) { return int(((f < 8 ? w[2] >> (4 * f) : w[3]) & 15u)); };
+    const bool on = has_row;
+    my_stage[on ? pre + pos(0) : kSpare] = r[0] + (rev ? s[1] : s[0]);
+    my_stage[on ? pre + pos(1) : kSpare] = r[1] + (rev ? s[0] : s[1]);
+    my_stage[on ? pre + pos(2) : kSpare] = r[2];
+    my_stage[on ? pre + pos(3) : kSpare] = r[3] + s[3];
+    my_stage[on ? pre + pos(4) : kSpare] = r[4];
+    my_stage[on ? pre + pos(5) : kSpare] = r[5];
+    my_stage[(on && has2) ? pre + pos(6) : kSpare] = s[2];
+    my_stage[(on && has2) ? pre + pos(7) : kSpare] = s[4];
+    my_stage[(on && has2) ? pre + pos(8) : kSpare] = s[5];
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    __builtin_amdgcn_wave_barrier();
+    p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+  }
+}
+
+template <typename T>
+static int launch_p2_rows(const void *coords, int quad_order, double alpha, double beta,
+                          const unsigned char *plan, const int64_t *z, int64_t nnz, void *vals,
+                          hipStream_t stream) {
+  TriTables tables;
+  if (!build_tri_tables(quad_order, int(sizeof(T)), &tables))
+    return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
+  if (z[0] + z[1] == 0) return TFEM_OK;
+  if (!coords || !plan || !vals) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (z[4] > 1024 || z[5] > 1024 || z[6] > kP2Block)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "P2 row plan exceeds the kernel's capacities");
+  const int64_t rb = int64_t(sizeof(T));
+  const int64_t extents[3] = {z[2] * 2 * rb, z[16], nnz * rb};
+  for (int64_t e : extents)
+    if (e < 0 || e >= (int64_t(1) << 32))
+      return fail(TFEM_ERR_INDEX_RANGE, "an array of %lld bytes does not fit the 32-bit offsets "
+                  "of the P2 row kernel", (long long)e);
+  const bool mass = beta != 0.0;
+  for (int kind = 0; kind < 2; ++kind) {
+    if (z[kind] == 0) continue;
+    P2RowArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.coords = static_cast<const T *>(coords);
+    a.plan = plan;
+    a.vals = static_cast<T *>(vals);
+    a.coords_bytes = unsigned(extents[0]);
+    a.plan_bytes = unsigned(extents[1]);
+    a.vals_bytes = unsigned(extents[2]);
+    a.off_desc = unsigned(z[10 + 3 * kind]);
+    a.off_rows = unsigned(z[11 + 3 * kind]);
+    a.off_gid = unsigned(z[12 + 3 * kind]);
+    a.n_tiles = int(z[kind]);
+    a.lds_vert = (int(z[4 + kind]) + 1) & ~1;
+    // row 0 (vertex DoF at p0) / row 3 (edge DoF (p0, p1)) of the constant maps, in T, sums in
+    // quadrature order like the reference's (integrand * dx).sum(-3)
+    const int row = kind == 0 ? 0 : 3;
+    for (int m = 0; m < 6; ++m) {
+      T ca = T(0), cb = T(0), cd = T(0), cm = T(0);
+      for (int q = 0; q < tables.nq; ++q) {
+        const T hw = T(tables.hw[q]);
+        const T r0 = T(tables.rgrad2[q][row][0]), r1 = T(tables.rgrad2[q][row][1]);
+        const T m0 = T(tables.rgrad2[q][m][0]), m1 = T(tables.rgrad2[q][m][1]);
+        ca = ca + hw * (r0 * m0);
+        cb = cb + hw * (r0 * m1 + r1 * m0);
+        cd = cd + hw * (r1 * m1);
+        cm = cm + hw * (T(tables.phi2[q][row]) * T(tables.phi2[q][m]));
+      }
+      a.ca[m] = T(alpha) * ca;
+      a.cb[m] = T(alpha) * cb;
+      a.cd[m] = T(alpha) * cd;
+      a.cm[m] = T(beta) * cm;
+    }
+    const int max_len = kind == 0 ? kP2VertexRowMax : kP2EdgeRowMax;
+    const size_t lds = size_t(2 * a.lds_vert) * sizeof(T) + size_t(kP2Waves) * size_t(64 * max_len + 2) * sizeof(T);
+    void *kernel = kind == 0 ? (mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true>)
+                                     : reinterpret_cast<void *>(k_p2_rows<T, 0, false>))
+                             : (mass ? reinterpret_cast<void *>(k_p2_rows<T, 1, true>)
+                                     : reinterpret_cast<void *>(k_p2_rows<T, 1, false>));
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const int per = int((z[kind] + 7) / 8);
+    const dim3 grid{unsigned(per * 8)}, block{unsigned(kP2Block)};
+    void *params[] = {&a};
+    hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, stream);
+    if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 row kernel launch: %s", hipGetErrorString(e));
+  }
+  return TFEM_OK;
+}
+
+}  // namespace tfem
+
+extern "C" {
+
+int tfem_p2_assemble_rows(const void *coords, int real_bytes, int quad_order, double alpha,
+                          double beta, const void *plan_device, const int64_t *plan_layout_host,
+                          void *vals, int64_t nnz, void *stream) {
+  using namespace tfem;
+  if (real_bytes != 4 && real_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (!plan_layout_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_layout_host is NULL");
+  const auto *plan = static_cast<const unsigned char *>(plan_device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return real_bytes == 8
+             ? launch_p2_rows<double>(coords, quad_order, alpha, beta, plan, plan_layout_host, nnz, vals, s)
+             : launch_p2_rows<float>(coords, quad_order, alpha, beta, plan, plan_layout_host, nnz, vals, s);
+}
+
+}  // extern "C"

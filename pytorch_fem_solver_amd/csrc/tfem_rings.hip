@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "tfem_common.hpp"
+#include "tfem_rowkit.hpp"
 
 // Reassociation is harmless here (see above: the row form is not the reference's operation
 // order anyway; parity is asserted at 1e-12 against the oracle).
@@ -35,15 +36,6 @@ namespace tfem {
 constexpr int kRingBlock = 256;             // lanes per workgroup = owned rows per tile
 constexpr int kRingWaves = kRingBlock / 64;
 constexpr int kRingVertCap = 1024;          // 10-bit local ids
-
-typedef unsigned int ru32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int ru32x3 __attribute__((ext_vector_type(3)));
-typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
-using ring_rsrc_t = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ ring_rsrc_t ring_rsrc(const void *p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, int(bytes), 0x00020000);
-}
 
 template <typename T>
 struct RingArgs {
@@ -71,23 +63,6 @@ __device__ __forceinline__ unsigned long long ring_stamp() {
   return t;
 }
 
-typedef const int32_t __attribute__((address_space(4))) *ring_const_i32;
-
-template <typename T>
-__device__ __forceinline__ T fast_rcp(T x) {
-  if constexpr (sizeof(T) == 8) {
-    // v_rcp_f64 is good to 4.6e-8 (tools/probe/rcp_accuracy.hip, measured on gfx950): one
-    // Newton step gives 2.2e-15, three orders inside the 1e-12 the parity tests assert
-    const double r = __builtin_amdgcn_rcp(x);
-    const double e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
-  } else {
-    float r = __builtin_amdgcn_rcpf(x);
-    const float e = __builtin_fmaf(-x, r, 1.0f);
-    return __builtin_fmaf(r, e, r);
-  }
-}
-
 // Field accessors of a row record (bit layout: tfem_rings_host.cpp).
 template <int SLOTS>
 struct RingRec {
@@ -110,28 +85,6 @@ struct RingRec {
                  : int((w[SLOTS == 7 ? 0 : 7] >> (4 * (i & 7))) & 15u);
   }
 };
-
-template <typename T>
-__device__ __forceinline__ void lds_xy(const T *xy, uint32_t lid, T &x, T &y) {
-  const T *p = xy + 2 * lid;  // one ds_read_b128 (double) / ds_read_b64 (float)
-  x = p[0];
-  y = p[1];
-}
-
-// +-w or 0 by the triangle flag of a slot (1: +w, 2: -w, 0: no triangle): integer selects on
-// the bit pattern, cheaper than selects between doubles.
-template <typename T>
-__device__ __forceinline__ T flag_weight(T w, uint32_t flag) {
-  if constexpr (sizeof(T) == 8) {
-    const ru32x2 b = __builtin_bit_cast(ru32x2, w);
-    const uint32_t lo = flag ? b.x : 0u;
-    const uint32_t hi = (flag ? b.y : 0u) ^ ((flag & 2u) << 30);
-    return __builtin_bit_cast(double, ru32x2{lo, hi});
-  } else {
-    const uint32_t b = __builtin_bit_cast(uint32_t, w);
-    return __builtin_bit_cast(float, (flag ? b : 0u) ^ ((flag & 2u) << 30));
-  }
-}
 
 // The row of local vertex `lv`: entries of the neighbour slots in off[0 .. k), the diagonal in
 // diag (off[k ..] is scratch).  With q_i = |e_i|^2 and p = e_i.e_next the three entries of a
@@ -205,20 +158,6 @@ __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLO
 // 64 * (SLOTS + 1) real ones absorb the slots a row does not have, so staging has no branches.
 template <typename T, int SLOTS>
 constexpr int ring_stage_entries() { return 64 * (SLOTS + 1) + 2; }
-
-// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS): Hillis-Steele
-// inside every row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row
-// read 0), then lane 15 of rows 0 and 2 is added to rows 1 and 3 (row_bcast:15) and lane 31 to
-// rows 2 and 3 (row_bcast:31).
-__device__ __forceinline__ int wave_inclusive_scan(int x) {
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);  // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);  // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);  // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);  // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
-  return x;
-}
 
 // Row entries -> the wave's stage (plain LDS stores).  `pre` = stage index of this lane's row;
 // returns the number of entries the wave staged (uniform).
@@ -322,18 +261,6 @@ __device__ __forceinline__ void ring_store(const T *stage, int total, int pre, i
     }
   }
   __builtin_amdgcn_wave_barrier();
-}
-
-template <typename T>
-__device__ __forceinline__ void ring_load_xy(ring_rsrc_t r, unsigned gid, T &x, T &y) {
-  if constexpr (sizeof(T) == 8) {
-    const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, gid * 16u, 0, 0);
-    x = __builtin_bit_cast(double, ru32x2{v.x, v.y});
-    y = __builtin_bit_cast(double, ru32x2{v.z, v.w});
-  } else {  // two dword loads: raw_buffer_load_b64 is miscompiled by this hipcc (tfem_tiles.hip)
-    x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, gid * 8u, 0, 0));
-    y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, gid * 8u + 4u, 0, 0));
-  }
 }
 
 template <int SLOTS>

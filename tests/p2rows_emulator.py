@@ -1,0 +1,127 @@
+"""numpy walk of a P2 row plan exactly as k_p2_rows does it (csrc/tfem_p2rows.hip): decode the
+vertex-row and edge-row records, evaluate one row of the element block per incident triangle
+from the tile-local coordinates through the constant maps A, B, D, M, place the entries by
+the recorded CSR positions, count the writes.  Test infrastructure for the host-side plan
+builder."""
+
+import numpy as np
+
+from oracle import assembly_oracle as orc
+
+
+def block_tables(integration_order):
+    """(A, B, D, M), each (6, 6): K_ab = A G11 + B G12 + D G22 (stiffness), M det (mass)."""
+    nodes, weights = orc.gauss_rule(integration_order)
+    bary = orc.barycentric_coordinates(nodes)
+    phi, rg = orc.shape_functions(2, bary, np.eye(2))  # identity inverse: reference gradients
+    hw = 0.5 * np.asarray(weights).reshape(-1)
+    phi = np.asarray(phi).reshape(-1, 6)
+    rg = np.asarray(rg).reshape(-1, 6, 2)
+    a = np.einsum("q,qa,qb->ab", hw, rg[:, :, 0], rg[:, :, 0])
+    b = np.einsum("q,qa,qb->ab", hw, rg[:, :, 0], rg[:, :, 1]) + np.einsum("q,qa,qb->ab", hw, rg[:, :, 1], rg[:, :, 0])
+    d = np.einsum("q,qa,qb->ab", hw, rg[:, :, 1], rg[:, :, 1])
+    m = np.einsum("q,qa,qb->ab", hw, phi, phi)
+    return a, b, d, m
+
+
+def _block_row(tab, row, p0, p1, p2, alpha, beta):
+    a, b, d, m = tab
+    e1, e2 = p1 - p0, p2 - p0
+    det = e1[0] * e2[1] - e1[1] * e2[0]
+    g11, g12, g22 = e2.dot(e2) / det, -e1.dot(e2) / det, e1.dot(e1) / det
+    return alpha * (a[row] * g11 + b[row] * g12 + d[row] * g22) + beta * m[row] * det
+
+
+def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, beta=0.0):
+    """Returns (vals, writes): CSR values and how often every CSR entry was written."""
+    tab = block_tables(integration_order)
+    nnz = int(rowptr[-1])
+    vals = np.full(nnz, np.nan)
+    writes = np.zeros(nnz, dtype=np.int64)
+    # ---- vertex rows
+    part = plan["vertex"]
+    rows = part["rows"].reshape(-1, 8).astype(np.uint64)
+    for d in part["desc"].reshape(-1, 16):
+        vert_off, n_vert, row_off = int(d[0]), int(d[1]), int(d[2])
+        ws = [int(d[3]), int(d[4]), int(d[5]), int(d[6]), int(d[7])]
+        assert ws[0] == 0 and all(0 <= y - x <= 64 for x, y in zip(ws[:-1], ws[1:]))
+        n_own = ws[4]
+        gid = part["vert_gid"][vert_off:vert_off + n_vert]
+        assert n_vert <= 512 and n_vert - n_own <= 256 and np.unique(gid).size == n_vert
+        xy = coords[gid]
+        for wv in range(4):
+            if ws[wv] < ws[wv + 1]:
+                assert np.all(np.diff(gid[ws[wv]:ws[wv + 1]]) == 1) and d[8 + wv] == gid[ws[wv]]
+                assert d[12 + wv] == rowptr[gid[ws[wv]]]
+        for r in range(n_own):
+            w = rows[row_off + r]
+            k = int((w[2] >> np.uint64(24)) & np.uint64(7))
+            v = int(gid[r])
+            start = int(rowptr[v])
+            if k == 0:
+                assert rowptr[v + 1] == start
+                continue
+            ids = [int((w[i // 3] >> np.uint64(10 * (i % 3))) & np.uint64(0x3FF)) for i in range(k)]
+            flags = [int((w[2] >> np.uint64(10 + 2 * i)) & np.uint64(3)) for i in range(k)]
+            field = lambda f: int((w[3 + f // 6] >> np.uint64(5 * (f % 6))) & np.uint64(31))  # noqa: E731
+            diag, vcol, ecol = 0.0, np.zeros(k), np.zeros(k)
+            out = {}
+            for i in range(k):
+                nxt = 0 if i + 1 == k else i + 1
+                if flags[i] == 0:
+                    continue
+                p1, p2 = (xy[ids[i]], xy[ids[nxt]]) if flags[i] == 1 else (xy[ids[nxt]], xy[ids[i]])
+                rr = _block_row(tab, 0, xy[r], p1, p2, alpha, beta)
+                i1, i2 = (i, nxt) if flags[i] == 1 else (nxt, i)
+                diag += rr[0]
+                vcol[i1] += rr[1]
+                vcol[i2] += rr[2]
+                ecol[i1] += rr[3]
+                ecol[i2] += rr[5]
+                out[field(14 + i)] = rr[4]
+            for i in range(k):
+                out[field(i)] = vcol[i]
+                out[field(7 + i)] = ecol[i]
+            out[int(w[2] >> np.uint64(27))] = diag
+            length = 1 + 2 * k + sum(1 for f in flags if f)
+            assert sorted(out) == list(range(length)) and rowptr[v + 1] - start == length
+            for pos, value in out.items():
+                vals[start + pos] = value
+                writes[start + pos] += 1
+    # ---- edge rows
+    part = plan["edge"]
+    rows = part["rows"].reshape(-1, 4).astype(np.uint64)
+    for d in part["desc"].reshape(-1, 16):
+        vert_off, n_vert, row_off = int(d[0]), int(d[1]), int(d[2])
+        ws = [int(d[3]), int(d[4]), int(d[5]), int(d[6]), int(d[7])]
+        n_own = ws[4]
+        gid = part["vert_gid"][vert_off:vert_off + n_vert]
+        assert n_vert <= 512 and np.unique(gid).size == n_vert
+        xy = coords[gid]
+        first = int(d[8])
+        for r in range(n_own):
+            w = rows[row_off + r]
+            row = first + r  # a tile's edge rows are consecutive DoFs
+            start = int(rowptr[row])
+            a, b, c = (int((w[0] >> np.uint64(s)) & np.uint64(0x3FF)) for s in (0, 10, 20))
+            dd = int(w[1] & np.uint64(0x3FF))
+            has2, rev = bool((w[1] >> np.uint64(10)) & np.uint64(1)), bool((w[1] >> np.uint64(11)) & np.uint64(1))
+            pos = [int((w[2] >> np.uint64(4 * f)) & np.uint64(15)) for f in range(8)] + [int(w[3] & np.uint64(15))]
+            rr = _block_row(tab, 3, xy[a], xy[b], xy[c], alpha, beta)
+            ss = np.zeros(6)
+            if has2:
+                o, t = (xy[b], xy[a]) if rev else (xy[a], xy[b])
+                ss = _block_row(tab, 3, o, t, xy[dd], alpha, beta)
+            out = {pos[0]: rr[0] + (ss[1] if rev else ss[0]), pos[1]: rr[1] + (ss[0] if rev else ss[1]),
+                   pos[2]: rr[2], pos[3]: rr[3] + ss[3], pos[4]: rr[4], pos[5]: rr[5]}
+            if has2:
+                out.update({pos[6]: ss[2], pos[7]: ss[4], pos[8]: ss[5]})
+            length = 9 if has2 else 6
+            assert sorted(out) == list(range(length)) and rowptr[row + 1] - start == length
+            for p, value in out.items():
+                vals[start + p] = value
+                writes[start + p] += 1
+        for wv in range(4):
+            if ws[wv] < ws[wv + 1]:
+                assert d[8 + wv] == first + ws[wv] and d[12 + wv] == rowptr[first + ws[wv]]
+    return vals, writes

@@ -642,3 +642,48 @@ def test_two_pass_gather_equals_atomic_scatter_and_is_reproducible(order):
     basis2._engine.kernel = "atomic"
     K2 = basis2.integrate_bilinear_form(convection_x, layout="csr")
     assert scaled_error(K.values.cpu(), K2.values.cpu()) <= 1e-14
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("form", ["stiffness", "stiffness_mass", "mass"])
+@pytest.mark.parametrize("order", [2, 4])
+def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order):
+    """k_p2_rows (owner-computes vertex rows and edge rows) on a mesh stored with mixed
+    orientation: equal to the oracle's P2 assembly entry by entry and to the element-block +
+    gather path."""
+    from pytorch_fem_solver_amd import dofs, meshgen
+
+    torch.set_default_dtype(dtype)
+    tol = TOL if dtype == torch.float64 else 2e-5
+    mesh_np = meshgen.unit_square(70, 0.25, 4)
+    tri = mesh_np["triangles"].copy()
+    flip = np.random.default_rng(5).random(tri.shape[0]) < 0.4
+    tri[flip] = tri[flip][:, [0, 2, 1]]
+    mesh_np["triangles"] = tri
+    ab = {"stiffness": (1.0, 0.0), "stiffness_mass": (1.0, 1.0), "mass": (0.0, 1.0)}[form]
+    got = {}
+    for kernel in ("rows", "gather"):
+        basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(2, order))
+        basis._engine.kernel = kernel
+        got[kernel] = basis._engine.bilinear(*ab)
+        assert basis._engine.kernel_name() == ("k_p2_rows" if kernel == "rows" else "k_p2_bilinear_atomic")
+    verts = mesh_np["vertices"] if dtype == torch.float64 else mesh_np["vertices"].astype(np.float32)
+    conn6, xy, _ = dofs.p2_dofs_numpy(mesh_np["vertices"], tri, mesh_np["edges"], mesh_np["edge_markers"],
+                                      mesh_np["vertex_markers"])
+    geo = orc.geometry(verts[tri], 2, order)
+    integrand = {"stiffness": orc.integrand_stiffness, "stiffness_mass": orc.integrand_stiffness_mass,
+                 "mass": orc.integrand_mass}[form](geo)
+    local = orc.integrate_local(integrand, geo["dx"])
+    _, colind, slots = orc.csr_pattern(conn6, xy.shape[0])
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    assert scaled_error(got["rows"].cpu().double(), want) <= tol
+    assert scaled_error(got["rows"].cpu().double(), got["gather"].cpu().double()) <= (1e-13 if dtype == torch.float64 else 2e-5)
+
+
+def test_p2_falls_back_to_gather_when_a_vertex_has_more_than_seven_neighbours():
+    from pytorch_fem_solver_amd import meshgen
+
+    basis = tf().Basis(tf().MeshTri(meshgen.delaunay_square(4000, 3)), tf().ElementTri(2, 2))
+    assert basis._engine.p2_plan() is None and basis._engine.kernel_name() == "k_p2_bilinear_atomic"
+    basis = tf().Basis(tf().MeshTri(meshgen.unit_square(30, 0.25, 1)), tf().ElementTri(2, 2))
+    assert basis._engine.kernel_name() == "k_p2_rows"

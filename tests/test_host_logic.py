@@ -13,6 +13,7 @@ from conftest import REPO, load_golden, mesh_from_golden, scaled_error
 from oracle import assembly_oracle as orc
 from plan_emulator import run_plan
 from ring_emulator import run_ring_plan
+from p2rows_emulator import run_p2_plan
 
 
 @pytest.fixture(autouse=True)
@@ -251,6 +252,42 @@ def test_ring_plan_rejects_fans_without_a_ring_form():
     rowptr, colind, _ = symbolic_host(tris, 5)
     with pytest.raises(NotImplementedError, match="fans"):
         ring_plan_host(tris, 5, verts, rowptr, colind)
+
+
+@pytest.mark.parametrize("kind", ["structured", "clockwise_mixed", "tiny"])
+@pytest.mark.parametrize("form", ["stiffness", "stiffness_mass"])
+def test_p2_row_plan_is_a_valid_exact_cover(kind, form):
+    """Walk the P2 row plan like k_p2_rows does (tests/p2rows_emulator.py): every CSR entry is
+    written exactly once and the values equal the oracle's P2 assembly."""
+    from pytorch_fem_solver_amd import dofs
+    from pytorch_fem_solver_amd.basis.engine import p2_plan_host, symbolic_host
+
+    mesh = _ring_case(kind)
+    conn6, xy, _ = dofs.p2_dofs_numpy(mesh["vertices"], mesh["triangles"], mesh["edges"],
+                                      mesh["edge_markers"], mesh["vertex_markers"])
+    nv, nd = mesh["vertices"].shape[0], xy.shape[0]
+    rowptr, colind, slots = symbolic_host(conn6, nd)
+    plan = p2_plan_host(conn6, nv, nd, mesh["vertices"], rowptr, colind)
+    beta = 1.0 if form == "stiffness_mass" else 0.0
+    vals, writes = run_p2_plan(plan, mesh["vertices"], rowptr, nv, 2, 1.0, beta)
+    assert (writes == 1).all()
+    geo = orc.geometry(mesh["vertices"][mesh["triangles"]], 2, 2)
+    integrand = orc.integrand_stiffness_mass(geo) if beta else orc.integrand_stiffness(geo)
+    local = orc.integrate_local(integrand, geo["dx"])
+    want = orc.assemble_csr_values(local, slots.reshape(-1, 6, 6), colind.shape[0])
+    assert scaled_error(vals, want) <= 1e-13
+
+
+def test_p2_row_plan_rejects_what_it_cannot_express():
+    from pytorch_fem_solver_amd import dofs, meshgen
+    from pytorch_fem_solver_amd.basis.engine import p2_plan_host, symbolic_host
+
+    mesh = meshgen.delaunay_square(3000, 2)  # vertices with more than 7 neighbours
+    conn6, xy, _ = dofs.p2_dofs_numpy(mesh["vertices"], mesh["triangles"], mesh["edges"],
+                                      mesh["edge_markers"], mesh["vertex_markers"])
+    rowptr, colind, _ = symbolic_host(conn6, xy.shape[0])
+    with pytest.raises(NotImplementedError):
+        p2_plan_host(conn6, mesh["vertices"].shape[0], xy.shape[0], mesh["vertices"], rowptr, colind)
 
 
 def test_tile_plan_rejects_rows_longer_than_16_entries():

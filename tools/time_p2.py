@@ -13,7 +13,7 @@ torch.set_default_dtype(torch.float64)
 torch.set_default_device("cuda")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 707
 mesh_np = meshgen.unit_square(n, 0.25, 0)
-for kernel in ("auto", "atomic"):
+for kernel in ("auto", "gather", "atomic"):
     basis = tf.Basis(tf.MeshTri(mesh_np), tf.ElementTri(2, 2))
     eng = basis._engine
     eng.kernel = kernel
@@ -31,6 +31,10 @@ for kernel in ("auto", "atomic"):
         times.append(a.elapsed_time(b) / 5 * 1e3)
     t = float(np.median(times))
     alg = 24 * ne + 16 * mesh_np["vertices"].shape[0] + 8 * nnz
-    how = "element blocks + gather (two launches)" if kernel == "auto" else "atomic scatter"
+    how = {"auto": "row kernels (k_p2_rows: vertex rows, edge rows)",
+           "gather": "element blocks + gather (two launches)", "atomic": "atomic scatter"}[kernel]
+    ref = vals if kernel == "auto" else ref
+    if kernel != "auto":
+        print("   max scaled difference to the row kernels: %.2e" % ((vals - ref).abs().max().item() / ref.abs().max().item()))
     print(f"P2 stiffness order 2: {ne} elements, {ndof} DoFs, nnz {nnz}: {how}: median {t:.1f} us "
           f"{ne / t:.0f} Melem/s, algorithmic {alg / ne:.0f} B/elem -> {alg / t / 1e3:.0f} GB/s = {alg / t / 8e6 * 100:.1f} % of 8 TB/s")
