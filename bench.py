@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | rings | tiles | atomic")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the short measurement of BASELINE.json's config 3 (P2, 1e6 elements)")
     return p.parse_args()
 
 
@@ -108,6 +110,40 @@ def cpu_baseline(n, order):
         "kind": "port",
         "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order}, C/OpenMP oracle "
         f"(oracle/assembly_oracle.c), best of 3",
+    }
+
+
+def p2_config3(device):
+    """BASELINE.json config 3 (P2, 6x6 blocks, S(707) = 999,698 elements) on this GPU: the
+    two launches of k_p2_rows (vertex rows, edge rows), timed with HIP events after the main
+    measurement.  Algorithmic bytes per SURVEY.md 8(d): 24 B conn + 16 B per vertex + 8 B per
+    CSR value."""
+    import pytorch_fem_solver_amd as tf
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(707, 0.25, 0)
+    basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(polynomial_order=2, integration_order=2))
+    eng = basis._engine
+    vals = eng.bilinear(1.0, 0.0)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        eng.bilinear(1.0, 0.0)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    ne, nv, nnz = mesh_np["triangles"].shape[0], mesh_np["vertices"].shape[0], int(vals.shape[0])
+    algo = 24 * ne + 16 * nv + 8 * nnz
+    return {
+        "workload": f"P2 stiffness K (CSR), order 2, mesh S(707,0.25,0) = {ne} elements, {eng.n_dofs} DoFs, nnz {nnz}",
+        "kernel": eng.kernel_name(),
+        "kernel_ms": ms,
+        "value": ne / ms / 1e3,
+        "unit": "Melements/s",
+        "algorithmic_bytes_per_launch": algo,
+        "achieved": algo / (ms * 1e-3) / 1e9,
+        "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
 
 
@@ -253,6 +289,8 @@ def main():
                 },
             },
         }
+        if world == 1 and not args.no_other_configs:
+            line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3(device)}
         if not args.no_cpu_baseline:
             torch.set_default_device("cpu")
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.order)
