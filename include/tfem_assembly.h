@@ -158,6 +158,12 @@ int tfem_csr_gather_map(const int32_t *slots_host, int64_t n_elems, int nn, int6
 int tfem_csr_gather(const void *local, int real_bytes, const int64_t *gptr, const int32_t *gsrc,
                     int64_t nnz, void *vals, void *stream);
 
+/* y = A x for the assembled CSR operator (DEVICE; x, y of n_rows entries).  The consumer of
+ * the assembled values: Krylov solves where the reference's dense reduce + torch.linalg.solve
+ * (abstract_basis.py:114-117,177-195) cannot go. */
+int tfem_csr_spmv(const int64_t *rowptr, const int32_t *colind, const void *vals, int real_bytes,
+                  int64_t n_rows, const void *x, void *y, void *stream);
+
 /* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
 int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,

@@ -180,9 +180,23 @@ class AbstractBasis(abc.ABC):
         """Zero vector (N, 1) (abstract_basis.py:173-175)."""
         return torch.zeros(self._basis_parameters["linear_form_shape"])
 
-    def solve(self, matrix, solution, vector, only_inner_dofs=True):
-        """Dense solve on the interior DoFs (abstract_basis.py:177-195); out of the
-        assembly kernel's scope."""
+    #: a CSR operator with more rows than this is solved by conjugate gradients on the CSR
+    #: values instead of the reference's dense solve (its dense copy would not fit)
+    DENSE_SOLVE_LIMIT = 20000
+
+    def solve(self, matrix, solution, vector, only_inner_dofs=True, method=None):
+        """Dense solve on the interior DoFs (abstract_basis.py:177-195).  A CSRMatrix beyond
+        DENSE_SOLVE_LIMIT rows (or method="cg") is solved by Jacobi-preconditioned conjugate
+        gradients on the CSR values (CSRMatrix.solve_cg; symmetric positive definite forms):
+        the step after the assembly for operators the reference cannot hold."""
+        if isinstance(matrix, CSRMatrix) and (method == "cg" or (method is None and matrix.shape[0] > self.DENSE_SOLVE_LIMIT)):
+            free = self._basis_parameters["inner_dofs"] if only_inner_dofs is True else None
+            x, _, _ = matrix.solve_cg(vector, free=free)
+            if free is None:
+                solution += x.reshape(solution.shape).to(solution.device)
+            else:
+                solution[free] += x.reshape(solution.shape)[free].to(solution.device)
+            return solution
         if only_inner_dofs is True:
             matrix = self.reduce(matrix)
             vector = self.reduce(vector)

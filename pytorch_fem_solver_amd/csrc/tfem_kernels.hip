@@ -595,6 +595,27 @@ __global__ __launch_bounds__(kBlock) void k_csr_gather(const T *local, const int
   vals[p] = acc;
 }
 
+// y = A x for the CSR operator (the consumer of the assembled values: Krylov solves on
+// operators far beyond the reference's dense torch.linalg.solve, abstract_basis.py:177-195).
+// Eight lanes per row (P1 rows hold ~7 entries, P2 rows 6-22): coalesced reads of vals/colind,
+// x through L2, one 8-byte store per row.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_csr_spmv(const int64_t *rowptr, const int32_t *colind,
+                                                      const T *vals, const T *x, T *y, int64_t n_rows) {
+  const int64_t gid = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t row = gid >> 3;
+  const int sub = int(gid & 7);
+  T acc = T(0);
+  if (row < n_rows) {
+    const int64_t end = rowptr[row + 1];
+    for (int64_t p = rowptr[row] + sub; p < end; p += 8) acc = acc + vals[p] * x[colind[p]];
+  }
+  acc = acc + __shfl_xor(acc, 4, 64);
+  acc = acc + __shfl_xor(acc, 2, 64);
+  acc = acc + __shfl_xor(acc, 1, 64);
+  if (row < n_rows && sub == 0) y[row] = acc;
+}
+
 // Interface exchange of the element-range sharding (parallel.py): entries of the local CSR
 // values / local vector that belong to DoFs shared with another rank are copied into the
 // packed buffer the ranks all-reduce (pack) and back (unpack).  One launch each.
@@ -771,6 +792,25 @@ int tfem_csr_gather(const void *local, int real_bytes, const int64_t *gptr, cons
   else
     hipLaunchKernelGGL(k_csr_gather<float>, dim3(blocks_for(nnz)), dim3(kBlock), 0, s,
                        static_cast<const float *>(local), gptr, gsrc, nnz, static_cast<float *>(vals));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_csr_spmv(const int64_t *rowptr, const int32_t *colind, const void *vals, int real_bytes,
+                  int64_t n_rows, const void *x, void *y, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (n_rows < 0 || (n_rows > 0 && (!rowptr || !x || !y)))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (n_rows == 0) return TFEM_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_csr_spmv<double>, dim3(blocks_for(8 * n_rows)), dim3(kBlock), 0, s, rowptr, colind,
+                       static_cast<const double *>(vals), static_cast<const double *>(x),
+                       static_cast<double *>(y), n_rows);
+  else
+    hipLaunchKernelGGL(k_csr_spmv<float>, dim3(blocks_for(8 * n_rows)), dim3(kBlock), 0, s, rowptr, colind,
+                       static_cast<const float *>(vals), static_cast<const float *>(x),
+                       static_cast<float *>(y), n_rows);
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

@@ -69,7 +69,72 @@ class CSRMatrix:
         return dense
 
     def matvec(self, x):
-        return self.to_sparse_csr() @ x
+        """A @ x for x of shape (N,) or (N, 1): libtfem_hip's CSR kernel on the GPU."""
+        if not self.values.is_cuda:
+            return self.to_sparse_csr() @ x
+        lib = _native.load()
+        flat = x.to(self.device, self.dtype).reshape(-1).contiguous()
+        if flat.shape[0] != self.shape[1]:
+            raise ValueError(f"matvec: x has {flat.shape[0]} entries, the operator {self.shape[1]} columns")
+        y = torch.empty(self.shape[0], dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                lib.tfem_csr_spmv(
+                    _native.ptr(self.crow_indices), _native.ptr(self.col_indices), _native.ptr(self.values),
+                    self.values.element_size(), self.shape[0], _native.ptr(flat), _native.ptr(y),
+                    _native.current_stream(self.device),
+                )
+            )
+        return y.reshape(x.shape)
+
+    def diagonal(self):
+        """Diagonal entries (0 where a row stores none)."""
+        n = self.shape[0]
+        counts = self.crow_indices[1:] - self.crow_indices[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=self.device), counts)
+        hit = self.col_indices.long() == rows
+        diag = torch.zeros(n, dtype=self.dtype, device=self.device)
+        diag[rows[hit]] = self.values[hit]
+        return diag
+
+    def solve_cg(self, b, free=None, x0=None, rtol=1e-12, maxiter=None):
+        """Jacobi-preconditioned conjugate gradients for the symmetric positive definite
+        operator restricted to the DoFs `free` (index tensor; the others keep x0's values, 0 by
+        default: homogeneous Dirichlet rows and columns are simply masked, no submatrix is
+        formed).  Returns (x, iterations, relative residual).  Stands where the reference's
+        dense `reduce` + `torch.linalg.solve` (abstract_basis.py:114-117,177-195) stops being
+        possible."""
+        n = self.shape[0]
+        shape = b.shape
+        b = b.to(self.device, self.dtype).reshape(-1)
+        mask = torch.ones(n, dtype=self.dtype, device=self.device)
+        if free is not None:
+            mask.zero_()
+            mask[free.to(self.device).reshape(-1)] = 1
+        x = torch.zeros(n, dtype=self.dtype, device=self.device) if x0 is None else x0.to(self.device, self.dtype).reshape(-1).clone()
+        inv_diag = mask / torch.where(self.diagonal() != 0, self.diagonal(), torch.ones_like(mask))
+        r = mask * (b - self.matvec(x))
+        x = x.clone()
+        z = inv_diag * r
+        p = z.clone()
+        rz = torch.dot(r, z)
+        b_norm = torch.linalg.vector_norm(mask * b).clamp_min(torch.finfo(self.dtype).tiny)
+        maxiter = maxiter or 10 * n
+        it, res = 0, float(torch.linalg.vector_norm(r) / b_norm)
+        while it < maxiter and res > rtol:
+            ap = mask * self.matvec(p)
+            alpha = rz / torch.dot(p, ap)
+            x += alpha * p
+            r -= alpha * ap
+            z = inv_diag * r
+            rz_new = torch.dot(r, z)
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+            it += 1
+            if it % 25 == 0 or it == maxiter:  # one host synchronisation every 25 iterations
+                res = float(torch.linalg.vector_norm(r) / b_norm)
+        res = float(torch.linalg.vector_norm(r) / b_norm)
+        return x.reshape(shape), it, res
 
     def __repr__(self):
         return f"CSRMatrix(shape={self.shape}, nnz={self.nnz}, dtype={self.dtype}, device={self.device})"

@@ -687,3 +687,25 @@ def test_p2_falls_back_to_gather_when_a_vertex_has_more_than_seven_neighbours():
     assert basis._engine.p2_plan() is None and basis._engine.kernel_name() == "k_p2_bilinear_atomic"
     basis = tf().Basis(tf().MeshTri(meshgen.unit_square(30, 0.25, 1)), tf().ElementTri(2, 2))
     assert basis._engine.kernel_name() == "k_p2_rows"
+
+
+def test_csr_spmv_and_cg_solve_against_the_dense_reference_solve():
+    """The consumer of large assembled operators: tfem_csr_spmv against torch's
+    dense product, and Basis.solve(method="cg") on the CSR operator against the reference's
+    dense reduce + torch.linalg.solve on the same Poisson problem."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(60, 0.25, 2)
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+    K = basis.integrate_bilinear_form(stiffness, layout="csr")
+    x = torch.rand(K.shape[0], 1)
+    assert scaled_error(K.matvec(x).cpu(), (K.to_dense() @ x).cpu()) <= 1e-14
+    f = basis.integrate_linear_form(load)
+    u_dense = basis.solve(K.to_dense(), basis.solution_tensor(), f)
+    u_cg = basis.solve(K, basis.solution_tensor(), f, method="cg")
+    assert scaled_error(u_cg.cpu(), u_dense.cpu()) <= 1e-9
+    # P2 operator (rows of 6-22 entries)
+    basis2 = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(2, 2))
+    K2 = basis2.integrate_bilinear_form(stiffness_mass, layout="csr")
+    y = torch.rand(K2.shape[0])
+    assert scaled_error(K2.matvec(y).cpu(), (K2.to_dense() @ y).cpu()) <= 1e-14
