@@ -262,7 +262,7 @@ int tfem_ring_capacity(int what);
  * fq != NULL: the same launch also writes the load vector fout[n_verts] = sum_e sum_q
  * fq[e][q] phi_i(x_q) dx_q from the user's source values fq (n_elems, Q) in ORIGINAL element
  * order (abstract_basis.py:95-112; every entry written once, 0 for a vertex without
- * elements). */
+ * elements).  vals == NULL with fq != NULL: the load vector alone. */
 int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
                            double alpha, double beta, const void *plan_device,
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,

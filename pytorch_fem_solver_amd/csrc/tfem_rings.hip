@@ -355,9 +355,10 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 // (abstract_basis.py:95-112 with basis.py:93-96): per slot the element id and the local index
 // `loc` of v in it come from the plan's row_elems, the Q source values are gathered while the
 // matrix part of the row is computed, l_loc(q) w_q / 2 is a 3 x Q table in LDS.
-template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG>
+template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
 __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   constexpr bool LOAD = QL > 0;
+  static_assert(KMAT || LOAD, "nothing to assemble");
   constexpr int kQPad = (QL + 1) & ~1;  // table row pitch: 16-byte aligned rows
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
       t2 = ring_stamp();
     }
     int total = 0, pre = 0;
-    if (!(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+    if (KMAT && !(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
     T facc = T(0);
     if (LOAD) {
 #pragma unroll
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     // ---- D ----
     if (t_n >= 0) park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
     if (timing) t5 = ring_stamp();
-    if (!(DBG && (a.flags & 8))) {
+    if (KMAT && !(DBG && (a.flags & 8))) {
       if (CHUNK) {  // one run per wave by construction, its CSR offset in the descriptor
         __builtin_amdgcn_wave_barrier();
         ring_store_run1<T, SLOTS, DBG>(my_stage, total, dc.rs0, r_vals, a.flags);
@@ -616,6 +617,18 @@ static int ring_cu_count() {
   return cached;
 }
 
+// load vector alone (vals == NULL): the matrix part of the row is dead code
+template <typename T, int SLOTS, bool CHUNK>
+static void *pick_ring_load_only(int nq) {
+  switch (nq) {
+    case 1: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 1, false, false>);
+    case 3: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 3, false, false>);
+    case 4: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 4, false, false>);
+    case 6: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 6, false, false>);
+    default: return nullptr;
+  }
+}
+
 template <typename T, int SLOTS, bool MASS, bool CHUNK>
 static void *pick_ring_q(int nq) {
   switch (nq) {
@@ -649,8 +662,9 @@ static int launch_rings(const RingLaunch &L) {
   const int64_t *z = L.layout;
   if (z[0] == 0) return TFEM_OK;
   const bool load = L.fq != nullptr;
-  if (!L.coords || !L.plan || !L.vals || (load && !L.fout))
-    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const bool kmat = L.vals != nullptr;
+  if (!kmat && !load) return fail(TFEM_ERR_INVALID_ARGUMENT, "nothing to assemble");
+  if (!L.coords || !L.plan || (load && !L.fout)) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] || z[14] > kRingHaloCap ||
       !((z[6] == 7 && z[7] == 4) || (z[6] == 15 && z[7] == 8)) || z[5] > z[6] + 1)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "ring plan exceeds the kernel's capacities");
@@ -660,7 +674,7 @@ static int launch_rings(const RingLaunch &L) {
   a.plan = L.plan;
   a.vals = static_cast<T *>(L.vals);
   const int64_t rb = int64_t(sizeof(T));
-  const int64_t extents[5] = {L.n_verts * 2 * rb, z[12], L.nnz * rb,
+  const int64_t extents[5] = {L.n_verts * 2 * rb, z[12], kmat ? L.nnz * rb : 0,
                               load ? L.n_elems * tables.nq * rb : 0, load ? L.n_verts * rb : 0};
   for (int64_t e : extents)
     if (e < 0 || e >= (int64_t(1) << 32))
@@ -703,9 +717,12 @@ static int launch_rings(const RingLaunch &L) {
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
   void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0);
+  if (!kmat)
+    kernel = slots == 7 ? (chunk ? pick_ring_load_only<T, 7, true>(tables.nq) : pick_ring_load_only<T, 7, false>(tables.nq))
+                        : (chunk ? pick_ring_load_only<T, 15, true>(tables.nq) : pick_ring_load_only<T, 15, false>(tables.nq));
   if (!kernel) return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   if constexpr (sizeof(T) == 8) {  // the ablation build exists for fp64 stiffness, 7 slots
-    if (L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {
+    if (kmat && L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {
       if (load)
         kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 4, true>)
                        : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, 4, true>);

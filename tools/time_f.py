@@ -18,7 +18,10 @@ def t(fn, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 print("K rings           %.1f us" % t(lambda: eng.bilinear(1.0, 0.0)))
-print("f tiles only      %.1f us" % t(lambda: eng.load(fq)))
+print("f rings only      %.1f us" % t(lambda: eng._assemble_rings(0.0, 0.0, fq, want_matrix=False)))
+print("f tiles only      %.1f us" % t(lambda: eng._assemble_tiles(0.0, 0.0, False, fq)[1]))
+fr, ft = eng._assemble_rings(0.0, 0.0, fq, want_matrix=False), eng._assemble_tiles(0.0, 0.0, False, fq)[1]
+print("f rings vs tiles  %.2e" % ((fr - ft).abs().max().item() / ft.abs().max().item()))
 print("K+f fused tiles   %.1f us" % t(lambda: eng._assemble_tiles(1.0, 0.0, True, fq)))
 print("K+f fused rings   %.1f us" % t(lambda: eng._assemble_rings(1.0, 0.0, fq)))
 for per_cu in (2, 3, 4):
