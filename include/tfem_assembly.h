@@ -235,16 +235,19 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *   create : TFEM_ERR_UNSUPPORTED when the triangles around some vertex do not form
  *            one closed fan or open fans (an edge with three triangles, duplicated or
  *            degenerate elements): use the tile plan for such a mesh.
- *   sizes  : fills layout[16]: [0] n_tiles [1] n_rows [2] n_local_verts
+ *   sizes  : fills layout[24]: [0] n_tiles [1] n_rows [2] n_local_verts
  *            [3] max local verts/tile [4] max owned rows/tile [5] max row length
  *            [6] neighbour slots per row record (7 | 15) [7] dwords per row record (4 | 8)
  *            [8..11] byte offsets of desc, rows, rowstart, vert_gid in the packed plan
  *            [12] bytes of the packed plan [13] 1 when every wave's rows are consecutive
  *            vertices (tiles made of chunks of the numbering) [14] max halo vertices/tile
- *            [15] byte offset of row_elems in the packed plan
- *   pack   : desc int32 (16 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
+ *            [15] byte offset of row_ecodes, [16] of tile_elems in the packed plan [17] max
+ *            elements per tile [18] 1 when every tile's elements fit the kernel's LDS stage
+ *            (the fused load vector needs it) [19] entries of tile_elems [20..23] reserved
+ *   pack   : desc int32 (20 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
  *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
- *            wave 0..3, CSR offset of the first row of wave 0..3) | row records
+ *            wave 0..3, CSR offset of the first row of wave 0..3, offset into tile_elems,
+ *            number of elements of the tile, 0, 0) | row records
  *            (bit layout: csrc/tfem_rings_host.cpp) | rowstart int32 (CSR offset of every
  *            owned row) | vert_gid int32 (owned rows first, ascending, then the halo)
  *   capacity: what = 0 owned rows per tile, 1 local vertices per tile
@@ -253,7 +256,7 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                           int64_t n_verts, const double *coords_host,
                           const int64_t *rowptr_host, const int32_t *colind_host,
                           int own_cap, int vert_cap, void **plan_out);
-int tfem_ring_plan_sizes(const void *plan, int64_t layout[16]);
+int tfem_ring_plan_sizes(const void *plan, int64_t layout[24]);
 int tfem_ring_plan_pack(const void *plan, void *blob_host);
 void tfem_ring_plan_destroy(void *plan);
 int tfem_ring_capacity(int what);

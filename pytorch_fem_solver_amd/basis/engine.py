@@ -149,7 +149,7 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
         )
     )
     try:
-        layout = np.zeros(16, dtype=np.int64)
+        layout = np.zeros(24, dtype=np.int64)
         _native.check(lib.tfem_ring_plan_sizes(handle, c_void_p(layout.ctypes.data)))
         blob = np.zeros(int(layout[12]), dtype=np.uint8)
         _native.check(lib.tfem_ring_plan_pack(handle, c_void_p(blob.ctypes.data)))
@@ -172,11 +172,13 @@ def unpack_ring_plan(blob, layout):
         "slots": z[6],
         "words": z[7],
         "chunked": bool(z[13]),
-        "desc": view(0, np.int32, 16 * z[0]),
+        "desc": view(0, np.int32, 20 * z[0]),
         "rows": view(1, np.uint32, z[7] * z[1]),
         "rowstart": view(2, np.int32, z[1]),
         "vert_gid": view(3, np.int32, z[2]),
-        "row_elems": np.frombuffer(blob, dtype=np.uint32, count=z[6] * z[1], offset=z[15]),
+        "row_ecodes": np.frombuffer(blob, dtype=np.uint32, count=((z[6] + 1) // 2) * z[1], offset=z[15]),
+        "tile_elems": np.frombuffer(blob, dtype=np.int32, count=z[19], offset=z[16]),
+        "elems_staged": bool(z[18]),
     }
 
 
@@ -360,6 +362,7 @@ class AssemblyEngine:
                         "blob": torch.from_numpy(plan["blob"]).to(self.device),
                         "layout": plan["layout"],
                         "chunked": plan["chunked"],
+                        "elems_staged": plan["elems_staged"],
                         "rows_per_run": plan["rowstart"].size / n_runs,
                     }
             if self._rings is False and self.kernel == "rings":
@@ -564,7 +567,7 @@ class AssemblyEngine:
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
         values fq (E, Q): one fused launch on the ring and tile paths, two launches
         otherwise."""
-        if self._use_rings():
+        if self._use_rings() and self.ring_plan()["elems_staged"]:
             return self._assemble_rings(alpha, beta, fq)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
@@ -575,7 +578,7 @@ class AssemblyEngine:
         # the vector alone: the element-form tile kernel reads every element's source values
         # once, coalesced (148 us at 1e7 elements); the row form gathers them per fan slot
         # (158 us) and is used only when there is no tile plan or it is asked for
-        if self.kernel == "rings" and self.ring_plan() is not None:
+        if self.kernel == "rings" and self.ring_plan() is not None and self.ring_plan()["elems_staged"]:
             return self._assemble_rings(0.0, 0.0, fq, want_matrix=False)
         if self.tile_plan() is not None:
             return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]

@@ -45,7 +45,8 @@ struct RingArgs {
   const T *fq;  // (n_elems, Q) source values, load vector only
   T *fout;
   unsigned coords_bytes, plan_bytes, vals_bytes, fq_bytes, fout_bytes;
-  unsigned off_desc, off_rows, off_rowstart, off_gid, off_elems;
+  unsigned off_desc, off_rows, off_rowstart, off_gid, off_elems, off_telems;
+  int lds_elem;   // element slots reserved in LDS per buffer (load vector)
   int n_tiles;
   int lds_vert;   // vertex slots reserved in LDS
   T stiff_w;      // alpha * sum_q w_q / 2
@@ -279,20 +280,20 @@ __device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, Ring
   }
 }
 
-// What one WAVE needs of a tile descriptor (16 ints, tfem_rings_host.cpp): the wave owns the
+// What one WAVE needs of a tile descriptor (20 ints, tfem_rings_host.cpp): the wave owns the
 // tile's rows [row0, row1), at most 64.  In a plan with consecutive-vertex tiles those rows
 // are the consecutive vertices gid0, gid0 + 1, ... and their CSR entries start at rs0: neither
 // the ids of the owned vertices nor the row offsets are read from memory.  Scalar loads with a
 // wave-uniform index (the plan is immutable during the launch: constant address space).
 struct RingDesc {
-  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0;
+  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0, elem_off, n_elem;
 };
 
 template <bool CHUNK>
 __device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigned off_desc, int tile,
                                               int wave) {
-  ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 64u * unsigned(tile));
-  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0};
+  ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 80u * unsigned(tile));
+  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17]};
   if (CHUNK) {
     r.gid0 = d[8 + wave];
     r.rs0 = d[12 + wave];
@@ -319,6 +320,7 @@ __device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigne
 // wrong by design and the product path never uses it.
 // ---------------------------------------------------------------------------------------
 constexpr int kRingHaloCap = kRingBlock;  // halo vertices per tile: one per lane
+constexpr int kRingElemPerLane = 3;       // elements staged per tile <= 3 * kRingBlock
 
 __device__ __forceinline__ void ring_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -351,19 +353,23 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 }
 
 // QL = 0: matrix only.  QL = Q > 0: the launch also forms the load vector
-//   f_v = sum over the triangles T of the fan  det_T * sum_q fq[T][q] l_loc(q) w_q / 2
-// (abstract_basis.py:95-112 with basis.py:93-96): per slot the element id and the local index
-// `loc` of v in it come from the plan's row_elems, the Q source values are gathered while the
-// matrix part of the row is computed, l_loc(q) w_q / 2 is a 3 x Q table in LDS.
+//   f_v = sum over the triangles T of the fan  det_T * g[T][loc],
+//   g[T][i] = sum_q fq[T][q] l_i(q) w_q / 2
+// (abstract_basis.py:95-112 with basis.py:93-96).  The source values of a tile's elements
+// (plan: tile_elems, ascending) are fetched ONCE per tile with coalesced 16-byte loads -- three
+// elements per lane, prefetched like the coordinates -- reduced to the three numbers g[T][.]
+// and staged in LDS (double-buffered); a row reads one of them per fan slot by the slot's
+// 16-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
+// instead is bound by the texture addresser: 14 scattered loads per row.)
 template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
 __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   constexpr bool LOAD = QL > 0;
   static_assert(KMAT || LOAD, "nothing to assemble");
-  constexpr int kQPad = (QL + 1) & ~1;  // table row pitch: 16-byte aligned rows
+  constexpr int kEW = (SLOTS + 1) / 2;  // dwords of slot codes per row
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
   T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
-  T *lam_tab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [3][kQPad]
+  T *gtab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [2][3 * lds_elem + 4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -384,10 +390,13 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   const ring_rsrc_t r_fout = ring_rsrc(a.fout, a.fout_bytes);
   constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
-  if (LOAD && tid < 3 * kQPad) lam_tab[tid] = (tid % kQPad) < QL ? a.lamw[tid / kQPad][tid % kQPad] : T(0);
+  if (LOAD && tid < 8)  // the spare entries slots without a triangle read (times a zero determinant)
+    gtab[(tid >> 2) * (3 * a.lds_elem + 4) + 3 * a.lds_elem + (tid & 3)] = T(0);
 
   RingRec<SLOTS> rec, rec_ld;
-  uint32_t se[LOAD ? SLOTS : 1], se_ld[LOAD ? SLOTS : 1];  // row_elems of the row (load vector)
+  uint32_t se[LOAD ? kEW : 1], se_ld[LOAD ? kEW : 1];  // slot codes of the row (load vector)
+  unsigned eid[LOAD ? kRingElemPerLane : 1], eid_ld[LOAD ? kRingElemPerLane : 1];  // element ids, like gid_*
+  T fqe_ld[LOAD ? kRingElemPerLane : 1][QL > 0 ? QL : 1];  // their source values
   unsigned gid_row = 0;                                    // vertex of this lane's current row
   int rowstart = 0, rowstart_ld = 0;
   unsigned gid_own = 0, gid_halo = 0;        // vertex ids of the tile whose coordinates load next
@@ -407,6 +416,43 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     g_halo = __builtin_amdgcn_raw_buffer_load_b32(
         r_plan, a.off_gid + (h < d.n_vert ? unsigned(d.vert_off + h) : kNone) * 4u, 0, 0);
   };
+  auto load_eids = [&](const RingDesc &d, unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
+    if (!LOAD) return;
+#pragma unroll
+    for (int j = 0; j < kRingElemPerLane; ++j) {
+      const int l = tid + j * kRingBlock;
+      e[LOAD ? j : 0] = __builtin_amdgcn_raw_buffer_load_b32(
+          r_plan, a.off_telems + (l < d.n_elem ? unsigned(d.elem_off + l) : kNone) * 4u, 0, 0);
+    }
+  };
+  // source values of the tile's elements by the ids that arrived an iteration earlier (lanes
+  // past the tile's last element carry the id 0 of the zero-filled load: harmless)
+  auto load_fq = [&](const RingDesc &d, const unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
+    if (!LOAD) return;
+#pragma unroll
+    for (int j = 0; j < kRingElemPerLane; ++j) {
+      const int l = tid + j * kRingBlock;
+      ring_load_fq<T, QL>(r_fq, l < d.n_elem ? e[LOAD ? j : 0] * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u,
+                          fqe_ld[LOAD ? j : 0]);
+    }
+  };
+  // g[T][i] = sum_q fq[T][q] l_i(q) w_q / 2 of the elements just loaded -> LDS
+  auto park_g = [&](const RingDesc &d, T *dst) {
+    if (!LOAD) return;
+#pragma unroll
+    for (int j = 0; j < kRingElemPerLane; ++j) {
+      const int l = tid + j * kRingBlock;
+      if (l < d.n_elem) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          T g = T(0);
+#pragma unroll
+          for (int q = 0; q < QL; ++q) g = g + fqe_ld[LOAD ? j : 0][q] * a.lamw[i][q];
+          dst[3 * l + i] = g;
+        }
+      }
+    }
+  };
   auto load_tile = [&](const RingDesc &d, unsigned g_own, unsigned g_halo) {
     const int r = d.row0 + lane;
     const unsigned row = r < d.row1 ? unsigned(d.row_off + r) : kNone;
@@ -414,20 +460,16 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
       ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
       if (!CHUNK)
         rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
-      if (LOAD) {  // SLOTS dwords per row: 16-byte pieces and one 12-byte piece
-        const unsigned eb = a.off_elems + row * unsigned(4 * SLOTS);
+      if (LOAD) {  // 16-bit slot codes: 4 (SLOTS 7) or 8 dwords per row
+        const unsigned eb = a.off_elems + row * unsigned(4 * kEW);
 #pragma unroll
-        for (int i = 0; i + 4 <= SLOTS; i += 4) {
+        for (int i = 0; i < kEW; i += 4) {
           const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, eb + unsigned(4 * i), 0, 0);
-          se_ld[i] = v.x;
-          se_ld[i + 1] = v.y;
-          se_ld[i + 2] = v.z;
-          se_ld[i + 3] = v.w;
+          se_ld[LOAD ? i : 0] = v.x;
+          se_ld[LOAD ? i + 1 : 0] = v.y;
+          se_ld[LOAD ? i + 2 : 0] = v.z;
+          se_ld[LOAD ? i + 3 : 0] = v.w;
         }
-        const ru32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r_plan, eb + unsigned(4 * (SLOTS - 3)), 0, 0);
-        se_ld[LOAD ? SLOTS - 3 : 0] = v.x;
-        se_ld[LOAD ? SLOTS - 2 : 0] = v.y;
-        se_ld[LOAD ? SLOTS - 1 : 0] = v.z;
       }
     }
     if (!(DBG && (a.flags & 4))) {
@@ -456,16 +498,24 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   RingDesc dnn = ring_desc<CHUNK>(a.plan, a.off_desc, t_nn >= 0 ? t_nn : t_c, wave);
   // prologue: tile 0 taken over, vertex ids of tile 1 in registers
   load_ids(dc, gid_own, gid_halo);
+  load_eids(dc, eid);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   load_tile(dc, gid_own, gid_halo);
-  if (t_n >= 0) load_ids(dn, gid_own_ld, gid_halo_ld);
+  load_fq(dc, eid);
+  if (t_n >= 0) {
+    load_ids(dn, gid_own_ld, gid_halo_ld);
+    load_eids(dn, eid_ld);
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   park(dc, xy);
+  park_g(dc, gtab);
   rec = rec_ld;
   rowstart = rowstart_ld;
   gid_row = gid_own;
 #pragma unroll
-  for (int i = 0; i < (LOAD ? SLOTS : 1); ++i) se[i] = se_ld[i];
+  for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
+#pragma unroll
+  for (int j = 0; j < (LOAD ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
   gid_own = gid_own_ld;
   gid_halo = gid_halo_ld;
   __syncthreads();
@@ -479,21 +529,15 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     // ---- A ----
     if (t_n >= 0) {
       load_tile(dn, gid_own, gid_halo);
-      if (t_nn >= 0) load_ids(dnn, gid_own_ld, gid_halo_ld);
+      load_fq(dn, eid);
+      if (t_nn >= 0) {
+        load_ids(dnn, gid_own_ld, gid_halo_ld);
+        load_eids(dnn, eid_ld);
+      }
     }
     if (timing) t1 = ring_stamp();
     // ---- B ----
     T off[SLOTS + 1], diag, sdets[SLOTS];
-    T fqv[LOAD ? SLOTS : 1][QL > 0 ? QL : 1];
-    uint32_t locs = 0;  // 2 bits per slot: local index of the row's vertex in the slot's element
-    if (LOAD) {  // the source values of the fan's elements: in flight during the matrix part
-#pragma unroll
-      for (int i = 0; i < SLOTS; ++i) {
-        const uint32_t e = se[i] & 0x3FFFFFFFu;
-        ring_load_fq<T, QL>(r_fq, e != 0x3FFFFFFFu ? e * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u, fqv[i]);
-        locs |= (se[i] >> 30) << (2 * i);
-      }
-    }
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
       ring_row<T, SLOTS, MASS, LOAD>(a, rec, unsigned(my_row < dc.row1 ? my_row : 0),
@@ -511,13 +555,14 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     if (KMAT && !(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
     T facc = T(0);
     if (LOAD) {
+      const T *g = gtab + cur * (3 * a.lds_elem + 4);
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
-        const T *w = lam_tab + ((locs >> (2 * i)) & 3u) * kQPad;
-        T sq = T(0);
-#pragma unroll
-        for (int q = 0; q < QL; ++q) sq = sq + fqv[i][q] * w[q];
-        facc = facc + sdets[i] * sq;
+        // code: tile-local element | loc << 10; 0xFFFF (no triangle) reads the spare entries
+        // behind the table, its determinant is 0
+        const uint32_t code = (se[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+        const uint32_t at = code == 0xFFFFu ? unsigned(3 * a.lds_elem) : 3u * (code & 0x3FFu) + (code >> 10);
+        facc = facc + sdets[i] * g[at];
       }
     }
     const int kk = rec.k();
@@ -531,7 +576,10 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
                                          // insertion knows the loads have landed
     if (timing) t4 = ring_stamp();
     // ---- D ----
-    if (t_n >= 0) park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
+    if (t_n >= 0) {
+      park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
+      park_g(dn, gtab + (cur ^ 1) * (3 * a.lds_elem + 4));
+    }
     if (timing) t5 = ring_stamp();
     if (KMAT && !(DBG && (a.flags & 8))) {
       if (CHUNK) {  // one run per wave by construction, its CSR offset in the descriptor
@@ -564,7 +612,9 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     rowstart = rowstart_ld;
     gid_row = gid_own;
 #pragma unroll
-    for (int i = 0; i < (LOAD ? SLOTS : 1); ++i) se[i] = se_ld[i];
+    for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
+#pragma unroll
+    for (int j = 0; j < (LOAD ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
     gid_own = gid_own_ld;
     gid_halo = gid_halo_ld;
     // ---- E ----
@@ -688,6 +738,10 @@ static int launch_rings(const RingLaunch &L) {
   a.fq_bytes = unsigned(extents[3]);
   a.fout_bytes = unsigned(extents[4]);
   a.off_elems = unsigned(z[15]);
+  a.off_telems = unsigned(z[16]);
+  if (load && (z[18] == 0 || z[17] > kRingElemPerLane * kRingBlock))
+    return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan has %lld elements: the fused load "
+                "vector stages at most %d", (long long)z[17], kRingElemPerLane * kRingBlock);
   for (int i = 0; i < 3; ++i)
     for (int q = 0; q < tables.nq; ++q) a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
   a.off_desc = unsigned(z[8]);
@@ -710,9 +764,10 @@ static int launch_rings(const RingLaunch &L) {
   a.mass_o = T(L.beta) * mo;
   const bool mass = L.beta != 0.0;
   const int slots = int(z[6]);
+  a.lds_elem = load ? int(z[17]) : 0;
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
                      size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) +
-                     (load ? size_t(3 * ((tables.nq + 1) & ~1)) * sizeof(T) : 0);
+                     (load ? size_t(2 * (3 * a.lds_elem + 4)) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;

@@ -36,21 +36,28 @@
 
 namespace tfem {
 
-constexpr int kRingDescStride = 16;
-constexpr int kRingLayoutLen = 16;
+constexpr int kRingDescStride = 20;
+constexpr int kRingLayoutLen = 24;
+constexpr int kRingElemCap = 768;  // elements staged per tile: three per lane of the kernel
 constexpr int kRingHaloCapHost = 256;  // halo vertices per tile: one per lane of the kernel
 
 struct RingPlan {
   int slots = 7, words = 4;
-  // per tile: vert_off, n_vert, row_off, then start_0 = 0, start_1, start_2, start_3,
+  // per tile (20 ints): vert_off, n_vert, row_off, then start_0 = 0, start_1, start_2, start_3,
   // start_4 = n_own (wave w of the workgroup owns the tile's rows [start_w, start_{w+1})),
-  // global id of the first row of wave 0..3, CSR offset of the first row of wave 0..3
+  // global id of the first row of wave 0..3, CSR offset of the first row of wave 0..3,
+  // offset into tile_elems, number of elements of the tile, 0, 0
   std::vector<int32_t> desc;
   std::vector<uint32_t> rows;     // `words` dwords per owned row
   std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
-  // load vector only: per owned row `slots` words = element of every slot's triangle |
-  // local index of the row's vertex in it << 30 (0x3FFFFFFF: no triangle)
-  std::vector<uint32_t> row_elems;
+  // load vector only.  tile_elems: the elements of every tile's fans (ascending per tile: their
+  // source values are fetched once per tile, coalesced, and staged in LDS); row_ecodes: per
+  // owned row one 16-bit code per slot, two per dword: tile-local element index | local index
+  // of the row's vertex in that element << 10 (0xFFFF: no triangle).
+  std::vector<int32_t> tile_elems;
+  std::vector<uint32_t> row_ecodes;
+  int32_t max_n_elem = 0;
+  bool elems_staged = true;  // false: some tile has more than kRingElemCap elements
   std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
   int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0, max_n_halo = 0;
   int64_t n_tiles = 0;
@@ -224,6 +231,8 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   // ---- tiles -----------------------------------------------------------------------------
   std::vector<int32_t> vert_stamp(size_t(n_verts), -1), vert_local(size_t(n_verts), 0);
   std::vector<int32_t> owned, fresh;
+  std::vector<int32_t> elem_stamp(size_t(n_elems), -1), elem_local(size_t(n_elems), 0);
+  std::vector<int32_t> fan_elem, fan_loc, elems_here;
   int32_t wave_start[5] = {0, 0, 0, 0, 0};  // of the tile under construction
   int32_t tile = 0;
   Fan fan;
@@ -259,6 +268,9 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         }
       }
     }
+    fan_elem.assign(size_t(n_own) * size_t(plan.slots), -1);
+    fan_loc.assign(size_t(n_own) * size_t(plan.slots), 0);
+    elems_here.clear();
     for (int l = 0; l < n_own; ++l) {
       const int32_t u = owned[size_t(l)];
       const int len = int(rowptr[u + 1] - rowptr[u]);
@@ -303,14 +315,40 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       }
       plan.rows.insert(plan.rows.end(), w, w + plan.words);
       plan.rowstart.push_back(int32_t(rowptr[u]));
-      for (int i = 0; i < plan.slots; ++i)
-        plan.row_elems.push_back(i < fan.k && fan.flag[i] != 0
-                                     ? uint32_t(fan.elem[i]) | uint32_t(fan.loc[i]) << 30
-                                     : 0x3FFFFFFFu);
+      for (int i = 0; i < fan.k; ++i)
+        if (fan.flag[i] != 0) {
+          fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] = fan.elem[i];
+          fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)] = fan.loc[i];
+          if (elem_stamp[size_t(fan.elem[i])] != tile) {
+            elem_stamp[size_t(fan.elem[i])] = tile;
+            elems_here.push_back(fan.elem[i]);
+          }
+        }
+    }
+    // the tile's elements, ascending (coalesced source-value loads), and the slot codes
+    std::sort(elems_here.begin(), elems_here.end());
+    const int32_t elem_off = int32_t(plan.tile_elems.size());
+    const int32_t n_elem = int32_t(elems_here.size());
+    if (n_elem > kRingElemCap) plan.elems_staged = false;
+    for (int32_t j = 0; j < n_elem; ++j) elem_local[size_t(elems_here[size_t(j)])] = j;
+    plan.tile_elems.insert(plan.tile_elems.end(), elems_here.begin(), elems_here.end());
+    plan.max_n_elem = std::max(plan.max_n_elem, n_elem);
+    const int ewords = (plan.slots + 1) / 2;
+    for (int l = 0; l < n_own; ++l) {
+      uint32_t ew[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 2 * ewords; ++i) {
+        uint32_t code = 0xFFFFu;
+        if (i < plan.slots && fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] >= 0) {
+          const int32_t le = elem_local[size_t(fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)])];
+          code = le < 1023 ? uint32_t(le) | uint32_t(fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)]) << 10 : 0xFFFFu;
+        }
+        ew[i / 2] |= code << (16 * (i % 2));
+      }
+      plan.row_ecodes.insert(plan.row_ecodes.end(), ew, ew + ewords);
     }
     int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
                                   wave_start[1], wave_start[2], wave_start[3], n_own,
-                                  0, 0, 0, 0, 0, 0, 0, 0};
+                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, 0, 0};
     plan.max_n_halo = std::max(plan.max_n_halo, next_local - n_own);
     for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
       if (wave_start[w] < wave_start[w + 1]) {
@@ -326,7 +364,11 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.desc.clear();
     plan.rows.clear();
     plan.rowstart.clear();
-    plan.row_elems.clear();
+    plan.tile_elems.clear();
+    plan.row_ecodes.clear();
+    plan.max_n_elem = 0;
+    plan.elems_staged = true;
+    std::fill(elem_stamp.begin(), elem_stamp.end(), -1);
     plan.vert_gid.clear();
     plan.max_n_vert = plan.max_n_own = plan.max_n_halo = 0;
     std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
@@ -468,15 +510,19 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[5] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+  const int64_t bytes[6] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
                             int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
-                            int64_t(p.row_elems.size()) * 4};
+                            int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4};
+  const int slot_of[6] = {8, 9, 10, 11, 15, 16};
   int64_t off = 0;
-  for (int i = 0; i < 5; ++i) {
-    layout[i < 4 ? 8 + i : 15] = off;
+  for (int i = 0; i < 6; ++i) {
+    layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
   layout[12] = off + 64;
+  layout[17] = p.max_n_elem;
+  layout[18] = p.elems_staged ? 1 : 0;
+  layout[19] = int64_t(p.tile_elems.size());
   layout[13] = p.chunked ? 1 : 0;
   layout[14] = p.max_n_halo;
 }
@@ -519,7 +565,7 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
   return TFEM_OK;
 }
 
-int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[16]) {
+int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[24]) {
   using namespace tfem;
   if (!plan_handle || !layout) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   ring_layout(*static_cast<const RingPlan *>(plan_handle), layout);
@@ -538,7 +584,8 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   std::memcpy(out + layout[9], p->rows.data(), p->rows.size() * 4);
   std::memcpy(out + layout[10], p->rowstart.data(), p->rowstart.size() * 4);
   std::memcpy(out + layout[11], p->vert_gid.data(), p->vert_gid.size() * 4);
-  std::memcpy(out + layout[15], p->row_elems.data(), p->row_elems.size() * 4);
+  std::memcpy(out + layout[15], p->row_ecodes.data(), p->row_ecodes.size() * 4);
+  std::memcpy(out + layout[16], p->tile_elems.data(), p->tile_elems.size() * 4);
   return TFEM_OK;
 }
 

@@ -34,13 +34,14 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
     how often every CSR entry was written, the number of rows covered and -- with source
     values fq (E, Q) and the table lamw (3, Q) = l_i(q) w_q / 2 -- the load vector."""
     slots, words = plan["slots"], plan["words"]
-    desc = plan["desc"].reshape(-1, 16)
+    desc = plan["desc"].reshape(-1, 20)
     rows = plan["rows"].reshape(-1, words)
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
     fvec = np.full(coords.shape[0], np.nan) if fq is not None else None
-    row_elems = plan["row_elems"].reshape(-1, slots)
+    ewords = (slots + 1) // 2
+    row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
     for d in desc:
         vert_off, n_vert, row_off, ws0, ws1, ws2, ws3, n_own = (int(x) for x in d[:8])
         wave_start = [ws0, ws1, ws2, ws3, n_own]
@@ -55,6 +56,9 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         assert np.unique(gid).size == n_vert
         xy = coords[gid]
         rec = decode_rows(rows[row_off:row_off + n_own], slots)
+        elem_off, n_elem = int(d[16]), int(d[17])
+        tile_elems = plan["tile_elems"][elem_off:elem_off + n_elem]
+        assert np.all(np.diff(tile_elems) > 0) and (n_elem <= 768 or not plan["elems_staged"])
         rowstart = plan["rowstart"][row_off:row_off + n_own]
         for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
             if b > a:  # what the consecutive-vertex kernel takes from the descriptor
@@ -72,12 +76,13 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
             off = np.zeros(k)
             diag = 0.0
             facc = 0.0
-            se = row_elems[row_off + r]
-            assert np.all(se[k:] == 0x3FFFFFFF)
+            ew = row_ecodes[row_off + r]
+            se = np.array([(int(ew[i // 2]) >> (16 * (i % 2))) & 0xFFFF for i in range(2 * ewords)])
+            assert np.all(se[k:] == 0xFFFF)
             for i in range(k):
                 nxt = 0 if i + 1 == k else i + 1
                 if flag[i] == 0:
-                    assert se[i] == 0x3FFFFFFF
+                    assert se[i] == 0xFFFF
                     continue
                 dvec = e[nxt] - e[i]
                 cross = e[i, 0] * e[nxt, 1] - e[i, 1] * e[nxt, 0]
@@ -87,7 +92,8 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
                 off[i] += -cs * dvec.dot(e[nxt]) + mass_o * sdet
                 off[nxt] += cs * dvec.dot(e[i]) + mass_o * sdet
                 if fvec is not None:
-                    elem, loc = int(se[i] & 0x3FFFFFFF), int(se[i] >> 30)
+                    elem, loc = int(tile_elems[se[i] & 0x3FF]), int(se[i] >> 10)
+                    assert loc < 3
                     facc += sdet * float(np.dot(fq[elem], lamw[loc]))
             targets = np.concatenate([rowstart[r] + pos[:k], [rowstart[r] + rec["dpos"][r]]])
             assert np.unique(targets).size == k + 1
