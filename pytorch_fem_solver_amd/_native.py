@@ -12,7 +12,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtfem_hip.so")
+#: TFEM_HIP_LIB: developer switch (an alternative build of the same library, e.g. other flags)
+LIB_PATH = os.environ.get("TFEM_HIP_LIB") or os.path.join(_HERE, "csrc", "libtfem_hip.so")
 
 _lib = None
 

@@ -575,10 +575,9 @@ class AssemblyEngine:
 
     def load(self, fq):
         """(N_dof,) vector of sum_q f_q phi_i dx_q; fq is (E, Q) on any device."""
-        # the vector alone: the element-form tile kernel reads every element's source values
-        # once, coalesced (148 us at 1e7 elements); the row form gathers them per fan slot
-        # (158 us) and is used only when there is no tile plan or it is asked for
-        if self.kernel == "rings" and self.ring_plan() is not None and self.ring_plan()["elems_staged"]:
+        # the vector alone: row form with the source values staged per tile (142 us at 1e7
+        # elements) when the ring plan applies, the element-form tile kernel (149 us) otherwise
+        if self.kernel != "tiles" and self._use_rings() and self.ring_plan()["elems_staged"]:
             return self._assemble_rings(0.0, 0.0, fq, want_matrix=False)
         if self.tile_plan() is not None:
             return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]

@@ -203,16 +203,19 @@ __device__ __forceinline__ void ring_store_run1(const T *stage, int total, int d
     } else if (128 * (u + 1) <= total || s0 + 1 < total) {  // first test is wave-uniform
       if constexpr (sizeof(T) == 8) {
         const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-        __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+        if (DBG && (flags & 1024))  // ablation: plain (temporal) stores
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, kStreamNT);
       } else {
         __builtin_amdgcn_raw_buffer_store_b64(
-            ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+            ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, kStreamNT);
       }
     } else if (s0 < total) {
       if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, kStreamNT);
       else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, kStreamNT);
     }
   }
 }
@@ -248,16 +251,16 @@ __device__ __forceinline__ void ring_store(const T *stage, int total, int pre, i
       } else if (s0 + 1 < e) {
         if constexpr (sizeof(T) == 8) {
           const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, kStreamNT);
         } else {
           __builtin_amdgcn_raw_buffer_store_b64(
-              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, kStreamNT);
         }
       } else if (s0 < e) {
         if constexpr (sizeof(T) == 8)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, kStreamNT);
         else
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, kStreamNT);
       }
     }
   }
@@ -266,13 +269,13 @@ __device__ __forceinline__ void ring_store(const T *stage, int total, int pre, i
 
 template <int SLOTS>
 __device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, RingRec<SLOTS> &rec) {
-  const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte, 0, 0);
+  const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte, 0, kStreamLoadNT);
   rec.w[0] = v.x;
   rec.w[1] = v.y;
   rec.w[2] = v.z;
   rec.w[3] = v.w;
   if constexpr (SLOTS == 15) {
-    const ru32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte + 16u, 0, 0);
+    const ru32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte + 16u, 0, kStreamLoadNT);
     rec.w[4] = u.x;
     rec.w[5] = u.y;
     rec.w[6] = u.z;
@@ -332,7 +335,7 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 #pragma unroll
   for (int q = 0; q + 1 < QL; q += 2) {
     if constexpr (sizeof(T) == 8) {
-      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, 0);
+      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, kStreamLoadNT);
       v[q] = __builtin_bit_cast(double, ru32x2{x.x, x.y});
       v[q + 1] = __builtin_bit_cast(double, ru32x2{x.z, x.w});
     } else {  // two dword loads: raw_buffer_load_b64 is miscompiled by this hipcc (tfem_tiles.hip)
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
         const unsigned eb = a.off_elems + row * unsigned(4 * kEW);
 #pragma unroll
         for (int i = 0; i < kEW; i += 4) {
-          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, eb + unsigned(4 * i), 0, 0);
+          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, eb + unsigned(4 * i), 0, kStreamLoadNT);
           se_ld[LOAD ? i : 0] = v.x;
           se_ld[LOAD ? i + 1 : 0] = v.y;
           se_ld[LOAD ? i + 2 : 0] = v.z;
@@ -593,9 +596,9 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     if (LOAD && dc.row0 + lane < dc.row1) {
       const unsigned byte = gid_row * unsigned(sizeof(T));
       if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, facc), r_fout, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, facc), r_fout, byte, 0, kStreamNT);
       else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, facc), r_fout, byte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, facc), r_fout, byte, 0, kStreamNT);
     }
     if (timing) {
       t6 = ring_stamp();

@@ -19,6 +19,20 @@ __device__ __forceinline__ ring_rsrc_t ring_rsrc(const void *p, unsigned bytes) 
 
 typedef const int32_t __attribute__((address_space(4))) *ring_const_i32;
 
+// Cache policy of the streaming stores (the CSR values, written once and not read again by the
+// kernel): bit 1 of the buffer instruction's aux operand = nt (non-temporal) on gfx950.
+// Measured on the P1 stiffness launch at 1e7 elements: 99.9 us with plain stores, 85-87 us with
+// nt -- the written lines no longer displace the coordinates and plan lines the kernel re-reads.
+// (Neutral for the fused K + f launch; the P2 row kernels and the tile kernel are 5-10 % slower
+// with it and keep plain stores.)
+constexpr int kStreamNT = 2;
+// The same hint on the read-once plan streams (row records, slot codes, element ids, source
+// values); build with -DTFEM_NT_LOADS=0 to compare.
+#ifndef TFEM_NT_LOADS
+#define TFEM_NT_LOADS 0
+#endif
+constexpr int kStreamLoadNT = TFEM_NT_LOADS ? 2 : 0;
+
 template <typename T>
 __device__ __forceinline__ T fast_rcp(T x) {
   if constexpr (sizeof(T) == 8) {

@@ -97,21 +97,25 @@ __device__ __forceinline__ T buf_load1(rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
   }
 }
+// Cache policy of the output stores.  Non-temporal stores (aux bit 1 = nt on gfx950) speed the
+// ring kernel up by 15 % (tfem_rowkit.hpp) but slow this kernel down (K + f 242 -> 264 us at 1e7
+// elements: its runs start at odd 8-byte entries and rely on L2 to merge partial lines).
+constexpr int kTileStoreNT = 0;
 template <typename T>
 __device__ __forceinline__ void buf_store1(rsrc_t r, unsigned off, T x) {
   if constexpr (sizeof(T) == 8)
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, off, 0, kTileStoreNT);
   else
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, off, 0, kTileStoreNT);
 }
 template <typename T>
 __device__ __forceinline__ void buf_store2(rsrc_t r, unsigned off, T x, T y) {
   if constexpr (sizeof(T) == 8) {
     const u32x2 a = __builtin_bit_cast(u32x2, x), b = __builtin_bit_cast(u32x2, y);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, b.x, b.y}, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, b.x, b.y}, r, off, 0, kTileStoreNT);
   } else {
     __builtin_amdgcn_raw_buffer_store_b64(
-        u32x2{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, off, 0, 0);
+        u32x2{__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, r, off, 0, kTileStoreNT);
   }
 }
 
