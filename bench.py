@@ -57,8 +57,8 @@ def measured_traffic(n, order, kernel, with_load):
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
     (profiles/r01_bench_pmc_summary.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE +
     WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), or None when no summary matches
-    the workload.  The instantiation is recognised by its name: `kernel<double, ..., Q, false>`
-    with Q = 0 for the matrix-only launch."""
+    the workload.  The instantiation is recognised by its name: the fifth template argument of
+    `k_p1_rings<double, SLOTS, MASS, CHUNK, Q, ...>` is Q, 0 for the matrix-only launch."""
     path = os.path.join(REPO, "profiles", "r01_bench_pmc_summary.json")
     try:
         with open(path) as fh:
@@ -69,7 +69,7 @@ def measured_traffic(n, order, kernel, with_load):
         for name, entry in summary["kernels"].items():
             if kernel + "<double" not in name:
                 continue
-            q = int(name.split(">")[0].split(",")[-2])
+            q = int(name.split("<", 1)[1].split(",")[4])  # k_p1_rings<T, SLOTS, MASS, CHUNK, Q, ...>
             if (q > 0) == with_load:
                 return float(entry["hbm_traffic_bytes_per_launch"]["total"])
     except (OSError, KeyError, ValueError, IndexError):
