@@ -41,7 +41,7 @@
 namespace tfem {
 
 constexpr int kP2LayoutLen = 24;
-constexpr int kP2VertCap = 512;   // local vertices per tile (10-bit ids, LDS budget)
+constexpr int kP2VertCap = 1000;  // local vertices per tile (10-bit ids)
 constexpr int kP2HaloCap = 256;   // halo vertices of a vertex tile: one per lane
 
 struct P2Plan {

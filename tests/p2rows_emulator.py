@@ -47,7 +47,7 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
         assert ws[0] == 0 and all(0 <= y - x <= 64 for x, y in zip(ws[:-1], ws[1:]))
         n_own = ws[4]
         gid = part["vert_gid"][vert_off:vert_off + n_vert]
-        assert n_vert <= 512 and n_vert - n_own <= 256 and np.unique(gid).size == n_vert
+        assert n_vert <= 1000 and n_vert - n_own <= 256 and np.unique(gid).size == n_vert
         xy = coords[gid]
         for wv in range(4):
             if ws[wv] < ws[wv + 1]:
@@ -96,7 +96,7 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
         ws = [int(d[3]), int(d[4]), int(d[5]), int(d[6]), int(d[7])]
         n_own = ws[4]
         gid = part["vert_gid"][vert_off:vert_off + n_vert]
-        assert n_vert <= 512 and np.unique(gid).size == n_vert
+        assert n_vert <= 1000 and np.unique(gid).size == n_vert
         xy = coords[gid]
         first = int(d[8])
         for r in range(n_own):
