@@ -15,9 +15,10 @@
 // The row's entries stay in registers; they are permuted into CSR order through a per-wave
 // LDS stage (plain stores) and leave as lane-contiguous global stores.
 //
-// HBM traffic per element (N_v = N_T / 2): row records 8 B + row offsets 2 B + vertex ids
-// ~2.7 B + coordinates ~10.5 B (halo re-reads included) + values 28 B ~ 51 B, against 48 B
-// algorithmic.
+// HBM traffic per element with consecutive-vertex tiles (N_v = N_T / 2; measured):
+// row records 8 B + halo vertex ids ~1 B + coordinates ~9.5 B (halo re-reads included) +
+// values 28.6 B = 47.6 B, against 48 B algorithmic: the 16-byte row records replace the
+// 24 bytes of connectivity the row's triangles take.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -835,7 +836,7 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
   L.fout = fout;
   // developer switches (tools/time_rings.py)
   if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
-  if (const char *v = std::getenv("TFEM_RINGS_DEBUG")) L.flags = std::atoi(v);
+  if (const char *v = std::getenv("TFEM_RINGS_DEBUG")) L.flags = std::atoi(v);  // ablation build
   return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
 }
 

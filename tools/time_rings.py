@@ -1,6 +1,12 @@
-"""Developer tool (GPU box): time the K-only kernels (rings / tiles) on the bench mesh.
+"""Developer tool (GPU box): time the K-only kernels (rings / tiles / atomic) on the bench
+mesh, with optional ablation, and print the in-kernel stamps of the ring kernel.
 
     python tools/time_rings.py [--n 2236] [--kernels rings,tiles]
+    kernel spec: name[:label[:workgroups per CU[:ablation flags[:zorder]]]], e.g.
+    rings:x:3 (3 workgroups per CU), rings:x::1 (no value stores), rings:x:::zorder
+    (Z-order vertex tiles).  Flags (TFEM_RINGS_DEBUG, results are wrong by design): 1 no value
+    stores, 2 no row arithmetic, 4 no coordinate loads, 8 no staging and stores, 16 no record
+    loads, 1024 plain instead of non-temporal stores.
 """
 import argparse
 import os
