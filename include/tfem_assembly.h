@@ -116,7 +116,11 @@ int tfem_tri_bilinear_csr(const void *coords, int real_bytes, const void *conn_g
 
 /* Fused linear form f(x_q) * v (tests/test_assembly.py:79-84): `fq` (n_elems, Q) are
  * the user's source values at the integration points.  out (n_dofs) is overwritten.
- * conn_dof (n_elems, n) are the global DoF ids (P1: n = 3, may equal conn_geo). */
+ * conn_dof (n_elems, n) are the global DoF ids (P1: n = 3, may equal conn_geo).
+ * conn_dof == NULL: LOCAL-VECTOR mode -- out (n, n_elems) receives the element vectors
+ * entry-major (out[i * n_elems + e]), n_dofs = n * n_elems; tfem_csr_gather with the gather
+ * map of conn_dof (tfem_csr_gather_map(conn_dof, n_elems, n, n_dofs, ...)) then forms the
+ * vector without atomics, in the reference's accumulation order. */
 int tfem_tri_load_vector(const void *coords, int real_bytes, const void *conn_geo,
                          const void *conn_dof, int idx_bytes, int64_t n_elems,
                          int64_t n_verts, int poly_order, int quad_order, const void *fq,
@@ -133,7 +137,8 @@ int tfem_tri_load_vector(const void *coords, int real_bytes, const void *conn_ge
  *   linear    (m = 1): adds into out[conn_dof]                 (:106-110)
  *   functional(m = 1): writes out[e] = sum_k sum_q (n_inner = n, usually 1)  (:65-72)
  * `vals` / `out` are overwritten.  tfem_reduce_scatter_bilinear with slots == NULL works in
- * LOCAL-BLOCK mode like tfem_tri_bilinear_csr.
+ * LOCAL-BLOCK mode like tfem_tri_bilinear_csr, tfem_reduce_scatter_linear with
+ * conn_dof == NULL in LOCAL-VECTOR mode like tfem_tri_load_vector.
  * ------------------------------------------------------------------------- */
 int tfem_reduce_scatter_bilinear(const void *integrand, int real_bytes, int64_t es, int64_t qs,
                                  const void *dx, int64_t n_elems, int n_quad, int n_local,

@@ -251,7 +251,8 @@ class AssemblyEngine:
         self._gather = None
         self._slots_host = None
         self._p2rows = None
-        #: "auto" (tile plan when the mesh allows it), "tiles" or "atomic"
+        #: "auto" (the best plan the mesh allows), "rings", "tiles", "rows" (P2 row kernels),
+        #: "gather" (element blocks / vectors + gather, no plan) or "atomic" (one-pass scatter)
         self.kernel = os.environ.get("TFEM_KERNEL", "auto")
 
     # ------------------------------------------------------------------ device state
@@ -304,8 +305,8 @@ class AssemblyEngine:
         if self._tiles is None:
             self._tiles = False
             eligible = (
-                self.kernel != "atomic" and self.poly_order == 1 and self.n_fractures == 0
-                and self._host_conn_geo.dim() == 2
+                self.kernel in ("auto", "tiles", "rings") and self.poly_order == 1
+                and self.n_fractures == 0 and self._host_conn_geo.dim() == 2
                 and torch.equal(self._host_conn_geo.reshape(-1).cpu().long(),
                                 self._host_conn_dof.reshape(-1).cpu().long())
             )
@@ -419,6 +420,29 @@ class AssemblyEngine:
             dev = self.device
             self._gather = (torch.from_numpy(gptr).to(dev), torch.from_numpy(gsrc[: slots.size]).to(dev))
         return self._gather
+
+    def gather_map_linear(self):
+        """The same for vectors: for every DoF the element-vector entries that add to it
+        (tfem_csr_gather_map applied to the DoF connectivity)."""
+        if getattr(self, "_gather_lin", None) is None:
+            conn = np.ascontiguousarray(self._host_conn_dof.cpu().numpy().astype(np.int32))
+            gptr = np.zeros(self.n_dofs + 1, dtype=np.int64)
+            gsrc = np.zeros(max(conn.size, 1), dtype=np.int32)
+            _native.check(self.lib.tfem_csr_gather_map(
+                c_void_p(conn.ctypes.data), self.n_elems, self.n_local, self.n_dofs,
+                c_void_p(gptr.ctypes.data), c_void_p(gsrc.ctypes.data)))
+            dev = self.device
+            self._gather_lin = (torch.from_numpy(gptr).to(dev), torch.from_numpy(gsrc[: conn.size]).to(dev))
+        return self._gather_lin
+
+    def _gather_local_vector(self, local):
+        gptr, gsrc = self.gather_map_linear()
+        out = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self.lib.tfem_csr_gather(
+                _native.ptr(local), self.real_bytes, _native.ptr(gptr), _native.ptr(gsrc), self.n_dofs,
+                _native.ptr(out), self._stream()))
+        return out
 
     def _gather_local(self, local):
         """CSR values from entry-major local blocks (n*n, E): one tfem_csr_gather launch."""
@@ -583,18 +607,22 @@ class AssemblyEngine:
             return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]
         d = self._inputs()
         fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
-        out = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+        # P2, fractures, meshes without a plan: element vectors -> gather (no atomics, the
+        # reference's accumulation order); TFEM_KERNEL=atomic keeps the one-pass atomic scatter
+        two_pass = self.kernel != "atomic"
+        out_len = self.n_local * self.n_elems if two_pass else self.n_dofs
+        out = torch.empty(out_len, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_tri_load_vector(
                     _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
-                    _native.ptr(d["conn_dof"]), 4, self.n_elems, self.coords_per_mesh,
-                    self.poly_order, self.quad_order, _native.ptr(fq), _native.ptr(out),
-                    self.n_dofs, _native.ptr(d["fdet"]), self.n_fractures, self.coords_per_mesh,
-                    self._stream(),
+                    None if two_pass else _native.ptr(d["conn_dof"]), 4, self.n_elems,
+                    self.coords_per_mesh, self.poly_order, self.quad_order, _native.ptr(fq),
+                    _native.ptr(out), out_len, _native.ptr(d["fdet"]), self.n_fractures,
+                    self.coords_per_mesh, self._stream(),
                 )
             )
-        return out
+        return self._gather_local_vector(out) if two_pass else out
 
     def _flatten_integrand(self, integrand, dx_shape, inner):
         """Broadcast against dx (..., Q, 1, 1) and view as (E, Q, *inner) with the inner
@@ -639,16 +667,18 @@ class AssemblyEngine:
         d = self._inputs()
         flat, es, qs = self._flatten_integrand(integrand, dx.shape, (n, 1))
         dxf = dx.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
-        out = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+        two_pass = self.kernel != "atomic"
+        out_len = n * self.n_elems if two_pass else self.n_dofs
+        out = torch.empty(out_len, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_reduce_scatter_linear(
                     _native.ptr(flat), self.real_bytes, es, qs, _native.ptr(dxf), self.n_elems,
-                    self.n_quad, n, _native.ptr(d["conn_dof"]), 4, _native.ptr(out), self.n_dofs,
-                    self._stream(),
+                    self.n_quad, n, None if two_pass else _native.ptr(d["conn_dof"]), 4,
+                    _native.ptr(out), out_len, self._stream(),
                 )
             )
-        return out
+        return self._gather_local_vector(out) if two_pass else out
 
     def reduce_functional(self, integrand, dx):
         integrand = integrand.to(self.device, self.dtype)

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(kBlock) void k_load_atomic(const TriArgs<T, I> a,
       const T phi = (N == 3) ? a.lam[q][i] : tab.phi[q][i];
       acc = acc + (f[q] * phi) * w[q];
     }
-    atomic_add(a.out + int64_t(a.conn_dof[N * e + i]), acc);
+    if (!a.conn_dof)
+      a.out[int64_t(i) * a.n_elems + e] = acc;  // local vectors, entry-major (N, n_elems)
+    else
+      atomic_add(a.out + int64_t(a.conn_dof[N * e + i]), acc);
   }
 }
 
@@ -360,7 +363,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce_linear(const T *integrand, in
   const T *w = dx + e * nq;
   T acc = T(0);
   for (int q = 0; q < nq; ++q) acc = acc + p[q * qs] * w[q];
-  atomic_add(out + int64_t(conn_dof[idx]), acc);
+  if (!conn_dof)
+    out[int64_t(k) * (n_entries / n) + e] = acc;  // local vectors, entry-major (n, n_elems)
+  else
+    atomic_add(out + int64_t(conn_dof[idx]), acc);
 }
 
 template <typename T>
@@ -505,12 +511,14 @@ static int run_load(const void *coords, const void *conn_geo, const void *conn_d
   if (int st = setup_args(a, coords, conn_geo, n_elems, n_verts, quad_order, fr, tables))
     return st;
   if (n_dofs > 0 && !out) return fail(TFEM_ERR_INVALID_ARGUMENT, "out is NULL");
-  if (n_elems > 0 && (!fq || !conn_dof))
-    return fail(TFEM_ERR_INVALID_ARGUMENT, "fq / conn_dof is NULL");
+  if (n_elems > 0 && !fq) return fail(TFEM_ERR_INVALID_ARGUMENT, "fq is NULL");
+  const int n_local = poly_order == 2 ? 6 : 3;
+  if (!conn_dof && n_dofs != n_local * n_elems)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "local-vector mode: out must hold %d * n_elems entries", n_local);
   a.conn_dof = static_cast<const I *>(conn_dof);
   a.fq = static_cast<const T *>(fq);
   a.out = static_cast<T *>(out);
-  if (n_dofs > 0) TFEM_HIP_CHECK(hipMemsetAsync(out, 0, size_t(n_dofs) * sizeof(T), stream));
+  if (conn_dof && n_dofs > 0) TFEM_HIP_CHECK(hipMemsetAsync(out, 0, size_t(n_dofs) * sizeof(T), stream));
   if (n_elems == 0) return TFEM_OK;
   P2Tables<T> p2;
   fill_p2(p2, tables);
@@ -727,11 +735,12 @@ int tfem_reduce_scatter_linear(const void *integrand, int real_bytes, int64_t es
   if (int st = check_common(real_bytes, idx_bytes, n_elems)) return st;
   if (n_quad < 1 || n_local < 1 || n_dofs < 0)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "bad n_quad / n_local / n_dofs");
-  if (n_elems > 0 && (!integrand || !dx || !conn_dof))
-    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL input");
+  if (n_elems > 0 && (!integrand || !dx)) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL input");
   if (n_dofs > 0 && !out) return fail(TFEM_ERR_INVALID_ARGUMENT, "out is NULL");
+  if (!conn_dof && n_dofs != int64_t(n_local) * n_elems)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "local-vector mode: out must hold n_local * n_elems entries");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (n_dofs > 0) TFEM_HIP_CHECK(hipMemsetAsync(out, 0, size_t(n_dofs) * size_t(real_bytes), s));
+  if (conn_dof && n_dofs > 0) TFEM_HIP_CHECK(hipMemsetAsync(out, 0, size_t(n_dofs) * size_t(real_bytes), s));
   if (n_elems == 0) return TFEM_OK;
   return TFEM_DISPATCH_TYPES(real_bytes, idx_bytes, run_reduce_linear, integrand, es, qs, dx,
                              n_elems, n_quad, n_local, conn_dof, out, s);

@@ -642,6 +642,19 @@ def test_two_pass_gather_equals_atomic_scatter_and_is_reproducible(order):
     basis2._engine.kernel = "atomic"
     K2 = basis2.integrate_bilinear_form(convection_x, layout="csr")
     assert scaled_error(K.values.cpu(), K2.values.cpu()) <= 1e-14
+    # linear forms: the P2 load vector (element vectors + gather) and the generic route
+    for p_order, q_order in ((2, 4), (1, 3)):
+        b_auto = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(p_order, q_order))
+        b_atomic = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(p_order, q_order))
+        b_atomic._engine.kernel = "atomic"
+        if p_order == 1:
+            b_auto._engine.kernel = "gather"  # no plan: element vectors + gather
+        f1, f1b, f2 = (b.integrate_linear_form(load) for b in (b_auto, b_auto, b_atomic))
+        assert torch.equal(f1, f1b)
+        assert scaled_error(f1.cpu(), f2.cpu()) <= 1e-14
+        r1 = b_auto.integrate_linear_form(weak_residual, grad_field)
+        r2 = b_atomic.integrate_linear_form(weak_residual, grad_field)
+        assert scaled_error(r1.cpu(), r2.cpu()) <= 1e-14
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
