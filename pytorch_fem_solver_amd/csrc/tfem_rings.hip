@@ -362,7 +362,7 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 // (abstract_basis.py:95-112 with basis.py:93-96).  The source values of a tile's elements
 // (plan: tile_elems, ascending) are fetched ONCE per tile with coalesced 16-byte loads -- three
 // elements per lane, prefetched like the coordinates -- reduced to the three numbers g[T][.]
-// and staged in LDS (double-buffered); a row reads one of them per fan slot by the slot's
+// and staged in LDS; a row reads one of them per fan slot by the slot's
 // 16-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
 // instead is bound by the texture addresser: 14 scattered loads per row.)
 template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
   T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
-  T *gtab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [2][3 * lds_elem + 4]
+  T *gtab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [3 * lds_elem + 4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   const ring_rsrc_t r_fout = ring_rsrc(a.fout, a.fout_bytes);
   constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
-  if (LOAD && tid < 8)  // the spare entries slots without a triangle read (times a zero determinant)
-    gtab[(tid >> 2) * (3 * a.lds_elem + 4) + 3 * a.lds_elem + (tid & 3)] = T(0);
+  if (LOAD && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
+    gtab[3 * a.lds_elem + tid] = T(0);
 
   RingRec<SLOTS> rec, rec_ld;
   uint32_t se[LOAD ? kEW : 1], se_ld[LOAD ? kEW : 1];  // slot codes of the row (load vector)
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     if (KMAT && !(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
     T facc = T(0);
     if (LOAD) {
-      const T *g = gtab + cur * (3 * a.lds_elem + 4);
+      const T *g = gtab;
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
         // code: tile-local element | loc << 10; 0xFFFF (no triangle) reads the spare entries
@@ -582,7 +582,12 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
     // ---- D ----
     if (t_n >= 0) {
       park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
-      park_g(dn, gtab + (cur ^ 1) * (3 * a.lds_elem + 4));
+      if (LOAD) {
+        // the element table is single-buffered (LDS for a third workgroup per CU): every wave
+        // has read tile k's entries (the loop above) before anybody overwrites them
+        ring_lds_barrier();
+        park_g(dn, gtab);
+      }
     }
     if (timing) t5 = ring_stamp();
     if (KMAT && !(DBG && (a.flags & 8))) {
@@ -771,7 +776,7 @@ static int launch_rings(const RingLaunch &L) {
   a.lds_elem = load ? int(z[17]) : 0;
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
                      size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) +
-                     (load ? size_t(2 * (3 * a.lds_elem + 4)) * sizeof(T) : 0);
+                     (load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
