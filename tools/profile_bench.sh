@@ -13,3 +13,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-form
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc3 -o run -- $CMD > $OUT/pmc3.log 2>&1
 python3 tools/summarize_pmc.py --pmc $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 --kernel k_p1_rings --out $OUT/pmc_summary.json \
   --command "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- $CMD (three passes)"
+# config 3 (P2 row kernels): kernel statistics and HBM traffic of tools/time_p2.py
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p2_stats -o run -- python3 tools/time_p2.py > $OUT/p2_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p2_pmc1 -o run -- python3 tools/time_p2.py > $OUT/p2_pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/p2_pmc2 -o run -- python3 tools/time_p2.py > $OUT/p2_pmc2.log 2>&1
+python3 tools/summarize_pmc.py --pmc $OUT/p2_pmc1 $OUT/p2_pmc2 --kernel k_p2_rows --out $OUT/p2_pmc_summary.json --n 707 --order 2 \
+  --command "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python3 tools/time_p2.py (two passes)"
