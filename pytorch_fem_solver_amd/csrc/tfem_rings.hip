@@ -373,7 +373,8 @@ __global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
   T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
-  T *gtab = stage + kRingWaves * ring_stage_entries<T, SLOTS>();  // [3 * lds_elem + 4]
+  // [3 * lds_elem + 4]; the load-vector-only instantiation has no stage
+  T *gtab = stage + (KMAT ? kRingWaves * ring_stage_entries<T, SLOTS>() : 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -775,7 +776,7 @@ static int launch_rings(const RingLaunch &L) {
   const int slots = int(z[6]);
   a.lds_elem = load ? int(z[17]) : 0;
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
-                     size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) +
+                     (kmat ? size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) : 0) +
                      (load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
