@@ -463,6 +463,8 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
             owned.push_back(v);
       }
       emit_tile();
+      // a numbering without locality shows early: stop building this tiling
+      if ((tile & 255) == 0 && plan.vert_gid.size() > 2 * plan.rowstart.size() + 4096) chunked = false;
     }
     if (status != TFEM_OK) return status;
     if (chunked && int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
