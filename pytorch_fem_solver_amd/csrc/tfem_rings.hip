@@ -330,13 +330,17 @@ __device__ __forceinline__ void ring_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef TFEM_NT_FQ
+#define TFEM_NT_FQ 0
+#endif
+constexpr int kFqLoadNT = TFEM_NT_FQ ? 2 : 0;
 // Q source values of one element (load vector): 16-byte loads where the type allows.
 template <typename T, int QL>
 __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v)[QL > 0 ? QL : 1]) {
 #pragma unroll
   for (int q = 0; q + 1 < QL; q += 2) {
     if constexpr (sizeof(T) == 8) {
-      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, kStreamLoadNT);
+      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, kFqLoadNT);
       v[q] = __builtin_bit_cast(double, ru32x2{x.x, x.y});
       v[q + 1] = __builtin_bit_cast(double, ru32x2{x.z, x.w});
     } else {  // two dword loads: raw_buffer_load_b64 is miscompiled by this hipcc (tfem_tiles.hip)
