@@ -279,7 +279,10 @@ def main():
                 "traffic": measured_traffic(n, args.order, engine.kernel_name(), True),
                 "algorithmic_bytes_per_launch": algo,
                 "kernel_ms": k_ms,
-                "launch": "fused K + f (52 B/element algorithmic)",
+                "launch": "fused K + f (52 B/element algorithmic, SURVEY.md 8(d); the Q source values "
+                "fq the launch must read, 8 Q B/element, are not part of that figure)",
+                "algorithmic_bytes_incl_fq": algo + 8 * nq * n_elems,
+                "frac_incl_fq": (algo + 8 * nq * n_elems) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "stiffness_only": {
                     "kernel_ms": k_only_ms,
                     "traffic": measured_traffic(n, args.order, engine.kernel_name(), False),
