@@ -370,7 +370,10 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 // 16-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
 // instead is bound by the texture addresser: 14 scattered loads per row.)
 template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
-__global__ __launch_bounds__(kRingBlock) void k_p1_rings(const RingArgs<T> a) {
+// The matrix-only 15-slot instantiations are asked for 3 waves per SIMD: left alone, hipcc's
+// scheduler hoists every LDS read of the unrolled fan loop and ends at 250 VGPRs (2 waves); with
+// the bound it needs 112-128 and nothing spills (the load-vector instantiations would spill).
+__global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_p1_rings(const RingArgs<T> a) {
   constexpr bool LOAD = QL > 0;
   static_assert(KMAT || LOAD, "nothing to assemble");
   constexpr int kEW = (SLOTS + 1) / 2;  // dwords of slot codes per row
