@@ -228,10 +228,19 @@ __device__ __forceinline__ void ring_store(const T *stage, int total, int pre, i
                                            ring_rsrc_t r_vals, int flags = 0) {
   const int lane = threadIdx.x & 63;
   __builtin_amdgcn_wave_barrier();
-  // lane r starts a run when its row does not continue the row of lane r - 1 (wave_shr:1)
+  // A row starts a run when the rows since the previous non-empty row are not one contiguous
+  // piece of the CSR array.  `breaks` = lanes whose row does not begin where the row of lane
+  // r - 1 ends (wave_shr:1; rows without entries -- isolated vertices -- take part with their
+  // offset: an empty row between two pieces must not glue them together).
   const int prev_end = __builtin_amdgcn_update_dpp(-1, rowstart + len, 0x138, 0xF, 0xF, false);
   const unsigned long long has_row = __ballot(len > 0);
-  unsigned long long starts = __ballot(len > 0 && prev_end != rowstart) | (has_row & (0ull - has_row));
+  const unsigned long long breaks = __ballot(prev_end != rowstart);
+  const unsigned long long below = (1ull << lane) - 1ull;           // lanes < this one
+  const unsigned long long ne_below = has_row & below;
+  // lanes in (previous non-empty lane, this lane]
+  const unsigned long long since = ne_below ? ~((2ull << (63 - __builtin_clzll(ne_below))) - 1ull) : ~0ull;
+  const bool start = len > 0 && ((breaks & since & (below | (1ull << lane))) != 0ull || ne_below == 0ull);
+  unsigned long long starts = __ballot(start);
   if ((starts & (starts - 1)) == 0) {
     const int delta = starts ? __builtin_amdgcn_readlane(rowstart, __builtin_ctzll(starts)) : 0;
     ring_store_run1<T, SLOTS, DBG>(stage, total, delta, r_vals, flags);

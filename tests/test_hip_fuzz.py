@@ -1,0 +1,123 @@
+"""Seeded random sweep of the P1 / P2 kernels against the oracle: Delaunay and structured
+meshes of random size with random element removal (open fans, several fans per vertex,
+isolated vertices), random orientation flips, random vertex / element renumbering, every
+kernel mode the engine offers.  Runs on a real MI355X only (-m gpu)."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import scaled_error
+from oracle import assembly_oracle as orc
+
+import os
+
+pytestmark = pytest.mark.gpu
+
+#: TFEM_FUZZ_SEEDS=n widens the sweep (developer runs); the default keeps the suite short
+N_P1 = int(os.environ.get("TFEM_FUZZ_SEEDS", "100"))
+N_P2 = max(N_P1 // 3, 8)
+
+
+@pytest.fixture(autouse=True)
+def _gpu_defaults():
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    torch.set_default_device("cuda")
+    yield
+    torch.set_default_device("cpu")
+    torch.set_default_dtype(torch.float32)
+
+
+def _random_mesh(rng):
+    from pytorch_fem_solver_amd import meshgen
+
+    if rng.random() < 0.5:
+        mesh = meshgen.unit_square(int(rng.integers(2, 60)), float(rng.uniform(0.0, 0.3)), int(rng.integers(1 << 30)))
+    else:
+        mesh = meshgen.delaunay_square(int(rng.integers(30, 4000)), int(rng.integers(1 << 30)))
+    verts, tris = mesh["vertices"].copy(), mesh["triangles"].copy()
+    if rng.random() < 0.5:  # holes: open fans, several fans per vertex, isolated vertices
+        keep = rng.random(tris.shape[0]) >= rng.uniform(0.02, 0.3)
+        if keep.sum() >= 1:
+            tris = tris[keep]
+    if rng.random() < 0.5:  # stored orientation
+        flip = rng.random(tris.shape[0]) < rng.uniform(0.05, 0.6)
+        tris[flip] = tris[flip][:, [0, 2, 1]]
+    if rng.random() < 0.5:  # rotate the local numbering of elements
+        shift = rng.integers(0, 3, size=tris.shape[0])
+        tris = np.stack([tris[np.arange(tris.shape[0]), (shift + j) % 3] for j in range(3)], axis=1)
+    if rng.random() < 0.4:  # numbering without locality
+        perm = rng.permutation(verts.shape[0])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.size)
+        verts, tris = verts[perm], inv[tris].astype(np.int32)
+    if rng.random() < 0.4:
+        tris = tris[rng.permutation(tris.shape[0])]
+    return verts, np.ascontiguousarray(tris.astype(np.int32))
+
+
+@pytest.mark.parametrize("seed", range(N_P1))
+def test_random_p1_meshes_every_kernel_mode(seed):
+    from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
+
+    rng = np.random.default_rng(1000 + seed)
+    verts, tris = _random_mesh(rng)
+    nv = verts.shape[0]
+    order = int(rng.integers(1, 5))
+    alpha, beta = (1.0, 0.0) if rng.random() < 0.4 else (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.0, 3.0)))
+    geo = orc.geometry(verts[tris], 1, order)
+    integrand = alpha * orc.integrand_stiffness(geo) + beta * orc.integrand_mass(geo)
+    local = orc.integrate_local(integrand, geo["dx"])
+    _, colind, slots = orc.csr_pattern(tris, nv)
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    fq_np = orc.source_sin_sin(geo["integration_points"])[..., 0, 0]
+    fl = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
+    want_f = orc.assemble_linear(fl, tris, nv).reshape(-1)
+    scale = max(float(np.abs(want).max()), 1e-300)
+    tried = []
+    for kernel in ("auto", "rings", "tiles", "gather", "atomic"):
+        eng = AssemblyEngine(torch.tensor(verts), torch.tensor(tris), torch.tensor(tris), nv, 1, order)
+        eng.kernel = kernel
+        try:
+            vals = eng.bilinear(alpha, beta)
+        except NotImplementedError:
+            assert kernel in ("rings", "tiles")  # a plan the mesh does not fit
+            continue
+        tried.append(kernel)
+        assert np.abs(vals.cpu().numpy() - want).max() / scale <= 1e-12, (seed, kernel, eng.kernel_name())
+        vals2, f = eng.assemble_system(alpha, beta, torch.tensor(fq_np))
+        assert np.abs(vals2.cpu().numpy() - want).max() / scale <= 1e-12, (seed, kernel, "system")
+        assert scaled_error(f.cpu().numpy().reshape(-1), want_f) <= 1e-12, (seed, kernel, "load")
+        assert scaled_error(eng.load(torch.tensor(fq_np)).cpu().numpy().reshape(-1), want_f) <= 1e-12
+    assert "auto" in tried and "gather" in tried and "atomic" in tried
+
+
+@pytest.mark.parametrize("seed", range(N_P2))
+def test_random_p2_meshes_every_kernel_mode(seed):
+    from pytorch_fem_solver_amd import dofs, meshgen
+    from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
+
+    rng = np.random.default_rng(2000 + seed)
+    if seed % 2 == 0:
+        mesh = meshgen.unit_square(int(rng.integers(2, 50)), float(rng.uniform(0.0, 0.3)), seed)
+    else:
+        mesh = meshgen.delaunay_square(int(rng.integers(50, 3000)), seed)
+    tris = mesh["triangles"].copy()
+    flip = rng.random(tris.shape[0]) < 0.3
+    tris[flip] = tris[flip][:, [0, 2, 1]]
+    conn6, xy, _ = dofs.p2_dofs_numpy(mesh["vertices"], tris, mesh["edges"], mesh["edge_markers"],
+                                      mesh["vertex_markers"])
+    order = int(rng.integers(2, 5))
+    alpha, beta = float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.0, 3.0))
+    geo = orc.geometry(mesh["vertices"][tris], 2, order)
+    integrand = alpha * orc.integrand_stiffness(geo) + beta * orc.integrand_mass(geo)
+    local = orc.integrate_local(integrand, geo["dx"])
+    _, colind, slots = orc.csr_pattern(conn6, xy.shape[0])
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    for kernel in ("auto", "gather", "atomic"):
+        eng = AssemblyEngine(torch.tensor(mesh["vertices"]), torch.tensor(tris), torch.tensor(conn6),
+                             xy.shape[0], 2, order)
+        eng.kernel = kernel
+        vals = eng.bilinear(alpha, beta)
+        assert scaled_error(vals.cpu().numpy(), want) <= 1e-12, (seed, kernel, eng.kernel_name())
