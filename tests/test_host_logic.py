@@ -290,6 +290,48 @@ def test_p2_row_plan_rejects_what_it_cannot_express():
         p2_plan_host(conn6, mesh["vertices"].shape[0], xy.shape[0], mesh["vertices"], rowptr, colind)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_meshes_through_the_plan_emulators(seed):
+    """Seeded random meshes (holes, flips, rotated local numbering, renumbering: the generator
+    of tests/test_hip_fuzz.py) through the host plan builders and the numpy emulators of the
+    ring and tile kernels: exact covers, values equal to the oracle's."""
+    from test_hip_fuzz import _random_mesh
+
+    from pytorch_fem_solver_amd.basis.engine import ring_plan_host, symbolic_host, tile_plan_host
+
+    rng = np.random.default_rng(500 + seed)
+    verts, tris = _random_mesh(rng)
+    if tris.shape[0] > 6000:
+        tris = tris[:6000]
+    nv = verts.shape[0]
+    rowptr, colind, slots = symbolic_host(tris, nv)
+    geo = orc.geometry(verts[tris], 1, 2)
+    local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
+    want = orc.assemble_csr_values(local, slots.reshape(-1, 3, 3), colind.shape[0])
+    try:
+        plan = ring_plan_host(tris, nv, verts, rowptr, colind)
+    except NotImplementedError:
+        plan = None
+    if plan is not None:
+        weights = np.asarray(orc.gauss_rule(2)[1]).reshape(-1)
+        bary = np.asarray(orc.barycentric_coordinates(orc.gauss_rule(2)[0])).reshape(-1, 3)
+        lamw = (bary * (0.5 * weights)[:, None]).T
+        fq = orc.source_sin_sin(geo["integration_points"])[..., 0, 0]
+        vals, writes, covered, fvec = run_ring_plan(plan, verts, colind.shape[0], 0.5 * weights.sum(), fq=fq, lamw=lamw)
+        assert covered == nv and (writes == 1).all()
+        assert scaled_error(vals, want) <= 1e-12
+        fl = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
+        assert scaled_error(fvec, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
+    try:
+        tplan = tile_plan_host(tris, nv, verts, rowptr, colind)
+    except NotImplementedError:
+        tplan = None
+    if tplan is not None:
+        vals, writes = run_plan(tplan, _stiffness_blocks, nv, colind.shape[0], verts)
+        assert (writes == 1).all() and scaled_error(vals, want) <= 1e-12
+    assert plan is not None or tplan is not None or int(np.diff(rowptr).max()) > 16
+
+
 def test_tile_plan_rejects_rows_longer_than_16_entries():
     from pytorch_fem_solver_amd.basis.engine import symbolic_host, tile_plan_host
 
