@@ -49,8 +49,9 @@ def _random_mesh(rng):
     if rng.random() < 0.5:  # rotate the local numbering of elements
         shift = rng.integers(0, 3, size=tris.shape[0])
         tris = np.stack([tris[np.arange(tris.shape[0]), (shift + j) % 3] for j in range(3)], axis=1)
-    if rng.random() < 0.4:  # numbering without locality
-        perm = rng.permutation(verts.shape[0])
+    renumber = rng.random()
+    if renumber < 0.7:  # numbering without locality (< 0.35) or along a Morton curve
+        perm = rng.permutation(verts.shape[0]) if renumber < 0.35 else meshgen.morton_order(verts)
         inv = np.empty_like(perm)
         inv[perm] = np.arange(perm.size)
         verts, tris = verts[perm], inv[tris].astype(np.int32)
