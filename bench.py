@@ -294,7 +294,7 @@ def main():
         }
         if world == 1 and not args.no_other_configs:
             line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3(device)}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
             torch.set_default_device("cpu")
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.order)
         print(json.dumps(line), flush=True)
