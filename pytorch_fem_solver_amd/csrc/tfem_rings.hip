@@ -54,7 +54,8 @@ struct RingArgs {
   T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
   T lamw[3][kMaxQuad];  // l_i(q) * w_q / 2 by local vertex i (load vector)
   int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
-                  // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 256 stamps
+                  // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
+                  // source-value loads, 64 no element-id loads, 128 no g staging, 256 stamps
   unsigned long long *stamps;  // ablation build, flag 256: 8 cycle sums per wave
 };
 
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
         r_plan, a.off_gid + (h < d.n_vert ? unsigned(d.vert_off + h) : kNone) * 4u, 0, 0);
   };
   auto load_eids = [&](const RingDesc &d, unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
-    if (!LOAD) return;
+    if (!LOAD || (DBG && (a.flags & 64))) return;  // ablation: no element-id loads
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
       const int l = tid + j * kRingBlock;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   // source values of the tile's elements by the ids that arrived an iteration earlier (lanes
   // past the tile's last element carry the id 0 of the zero-filled load: harmless)
   auto load_fq = [&](const RingDesc &d, const unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
-    if (!LOAD) return;
+    if (!LOAD || (DBG && (a.flags & 32))) return;  // ablation: no source-value loads
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
       const int l = tid + j * kRingBlock;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   };
   // g[T][i] = sum_q fq[T][q] l_i(q) w_q / 2 of the elements just loaded -> LDS
   auto park_g = [&](const RingDesc &d, T *dst) {
-    if (!LOAD) return;
+    if (!LOAD || (DBG && (a.flags & 128))) return;  // ablation: no reduction / staging of g
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
       const int l = tid + j * kRingBlock;

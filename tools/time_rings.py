@@ -107,6 +107,25 @@ if "rings" in args.kernels:
     fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
     del pts
     fout = torch.empty(eng.n_dofs)
+    # the fused K + f launch with parts switched off (ablation build; wrong results by design)
+    for label, extra in (("K + f full", 0), ("no value / f stores", 1), ("no source-value loads", 32),
+                         ("no element ids + source values", 96), ("no g staging", 128), ("no row arithmetic", 2),
+                         ("no coordinate loads", 4), ("no record / code loads", 16), ("loads only (2+8+128)", 138)):
+        def run_fused():
+            _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
+                             _native.ptr(rings["blob"]), ctypes.c_void_p(rings["layout"].ctypes.data),
+                             _native.ptr(vals), ctypes.c_int64(nnz), _native.current_stream(eng.device),
+                             512 | extra, 0, None, _native.ptr(fq), ctypes.c_int64(eng.n_elems), _native.ptr(fout)))
+        for _ in range(3):
+            run_fused()
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(20):
+            run_fused()
+        eb.record()
+        torch.cuda.synchronize()
+        print(f"  fused, {label:34s} {ea.elapsed_time(eb) / 20 * 1e3:8.1f} us")
     print("cycles per tile per wave:   " + " ".join(f"{n:>8s}" for n in names) + "    total")
     for label, extra, load in (("full", 0, False), ("no stores", 1, False), ("no arithmetic", 2, False),
                                ("no gather", 4, False), ("no stores+arith", 3, False),
