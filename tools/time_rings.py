@@ -110,12 +110,14 @@ if "rings" in args.kernels:
     # the fused K + f launch with parts switched off (ablation build; wrong results by design)
     for label, extra in (("K + f full", 0), ("no value / f stores", 1), ("no source-value loads", 32),
                          ("no element ids + source values", 96), ("no g staging", 128), ("no row arithmetic", 2),
-                         ("no coordinate loads", 4), ("no record / code loads", 16), ("loads only (2+8+128)", 138)):
+                         ("no coordinate loads", 4), ("no record / code loads", 16), ("loads only (2+8+128)", 138),
+                         ("loads only, 2 workgroups/CU", 138 | 2 << 16), ("loads only, 1 workgroup/CU", 138 | 1 << 16)):
         def run_fused():
             _native.check(fn(_native.ptr(d["coords"]), ctypes.c_int64(eng.n_dofs), 3,
                              _native.ptr(rings["blob"]), ctypes.c_void_p(rings["layout"].ctypes.data),
                              _native.ptr(vals), ctypes.c_int64(nnz), _native.current_stream(eng.device),
-                             512 | extra, 0, None, _native.ptr(fq), ctypes.c_int64(eng.n_elems), _native.ptr(fout)))
+                             512 | (extra & 0xFFFF), extra >> 16, None, _native.ptr(fq), ctypes.c_int64(eng.n_elems),
+                             _native.ptr(fout)))
         for _ in range(3):
             run_fused()
         torch.cuda.synchronize()
