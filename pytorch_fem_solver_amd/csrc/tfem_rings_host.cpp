@@ -420,11 +420,19 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     }
     std::sort(corder.begin(), corder.end());
     chunked = true;
+    // pass 1: group the chunks into tiles (neighbouring chunks along the curve while the local
+    // vertices fit); pass 2: emit the tiles in the order of their first vertex, so that the
+    // tiles the resident workgroups work on at the same time cover long contiguous ranges of
+    // the coordinate, source-value and CSR value arrays (TFEM_RING_ORDER=curve keeps curve order)
     std::vector<int32_t> tile_chunks, chunk_fresh;
+    std::vector<std::vector<int32_t>> groups;
     int64_t ccursor = 0;
-    while (ccursor < n_chunks && chunked && status == TFEM_OK) {
+    int32_t probe = -2;  // stamp values of pass 1: negative, distinct from every tile id
+    int64_t probe_local = 0, probe_rows = 0;
+    while (ccursor < n_chunks && chunked) {
       tile_chunks.clear();
       int n_local = 0, n_owned_rows = 0;
+      --probe;
       while (ccursor < n_chunks && int(tile_chunks.size()) < chunks_per_tile) {
         const int64_t c = corder[size_t(ccursor)].second;
         const int64_t v0 = chunk_first[size_t(c)], v1 = chunk_first[size_t(c) + 1];
@@ -433,13 +441,15 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         int added = 0;
         chunk_fresh.clear();
         for (int64_t v = v0; v < v1; ++v) {
-          fresh.clear();
-          collect_fresh(int32_t(v));
-          for (int32_t w : fresh) {
-            vert_stamp[size_t(w)] = tile;
-            chunk_fresh.push_back(w);
-          }
-          added += int(fresh.size());
+          auto touch = [&](int32_t w) {
+            if (vert_stamp[size_t(w)] != probe) {
+              vert_stamp[size_t(w)] = probe;
+              chunk_fresh.push_back(w);
+              ++added;
+            }
+          };
+          touch(int32_t(v));
+          for (int64_t p = rowptr[v]; p < rowptr[v + 1]; ++p) touch(colind[p]);
         }
         const int owned_after = n_owned_rows + int(v1 - v0);
         if (n_local + added > vert_cap || n_local + added - owned_after > kRingHaloCapHost) {
@@ -454,17 +464,38 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       }
       if (!chunked) break;
       std::sort(tile_chunks.begin(), tile_chunks.end());
-      owned.clear();
-      for (int w = 0; w < 5; ++w) {
-        wave_start[w] = int32_t(owned.size());  // one chunk per wave
-        if (w < int(tile_chunks.size()))
-          for (int32_t v = chunk_first[size_t(tile_chunks[size_t(w)])];
-               v < chunk_first[size_t(tile_chunks[size_t(w)]) + 1]; ++v)
-            owned.push_back(v);
-      }
-      emit_tile();
+      groups.push_back(tile_chunks);
+      probe_local += n_local;
+      probe_rows += n_owned_rows;
       // a numbering without locality shows early: stop building this tiling
-      if ((tile & 255) == 0 && plan.vert_gid.size() > 2 * plan.rowstart.size() + 4096) chunked = false;
+      if ((groups.size() & 255) == 0 && probe_local > 2 * probe_rows + 4096) chunked = false;
+    }
+    if (chunked && probe_local > 2 * n_verts) chunked = false;
+    if (chunked) {
+      const char *ord = std::getenv("TFEM_RING_ORDER");
+      if (!(ord && std::strcmp(ord, "curve") == 0))
+        std::sort(groups.begin(), groups.end(),
+                  [](const std::vector<int32_t> &x, const std::vector<int32_t> &y) { return x[0] < y[0]; });
+      std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
+      for (const std::vector<int32_t> &g : groups) {
+        owned.clear();
+        for (int w = 0; w < 5; ++w) {
+          wave_start[w] = int32_t(owned.size());  // one chunk per wave
+          if (w < int(g.size()))
+            for (int32_t v = chunk_first[size_t(g[size_t(w)])]; v < chunk_first[size_t(g[size_t(w)]) + 1]; ++v)
+              owned.push_back(v);
+        }
+        // the tile's local vertices: stamped with the tile id, as emit_tile expects
+        for (int32_t u : owned) {
+          fresh.clear();
+          collect_fresh(u);
+          for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
+        }
+        emit_tile();
+        if (status != TFEM_OK) return status;
+      }
+    } else {
+      std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
     }
     if (status != TFEM_OK) return status;
     if (chunked && int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
