@@ -280,6 +280,7 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
     }
     std::sort(corder.begin(), corder.end());
     std::vector<int32_t> tile_chunks, fresh, owned;
+    std::vector<std::vector<int32_t>> groups;
     P2Fan fan;
     int64_t cursor = 0;
     while (cursor < n_chunks) {
@@ -315,6 +316,20 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
         ++cursor;
       }
       std::sort(tile_chunks.begin(), tile_chunks.end());
+      groups.push_back(tile_chunks);
+    }
+    // the tiles in the order of their first vertex: the tiles the workgroups work on at the same
+    // time cover long contiguous ranges of the coordinate and CSR value arrays
+    std::sort(groups.begin(), groups.end(),
+              [](const std::vector<int32_t> &x, const std::vector<int32_t> &y) { return x[0] < y[0]; });
+    for (const std::vector<int32_t> &group : groups) {
+      tile_chunks = group;
+      const int32_t tag = serial++;
+      for (int32_t c : tile_chunks)
+        for (int64_t v = chunk_first[size_t(c)]; v < chunk_first[size_t(c) + 1]; ++v) {
+          stamp[size_t(v)] = tag;
+          for (int64_t p = rowptr[v]; p < rowptr[v + 1] && colind[p] < n_verts; ++p) stamp[size_t(colind[p])] = tag;
+        }
       owned.clear();
       int32_t ws[5];
       for (int w = 0; w < 5; ++w) {
