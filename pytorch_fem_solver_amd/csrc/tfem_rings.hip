@@ -49,7 +49,8 @@ struct RingArgs {
   unsigned off_desc, off_rows, off_rowstart, off_gid, off_elems, off_telems;
   int lds_elem;   // element slots reserved in LDS per buffer (load vector)
   int xcd_interleave;  // 0: every XCD walks its own contiguous eighth of the tile list
-                       // 1: tile t goes to XCD t % 8 (one front across the chip; experiment)
+                       // G > 0: the tile list is dealt to the XCDs in blocks of G tiles (one
+                       //        front of tiles across the chip)
   int n_tiles;
   int lds_vert;   // vertex slots reserved in LDS
   T stiff_w;      // alpha * sum_q w_q / 2
@@ -398,13 +399,16 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   T *my_stage = stage + wave * ring_stage_entries<T, SLOTS>();
-  const int per = (a.n_tiles + 7) / 8;
+  // tiles per XCD, a whole number of blocks when the tile list is dealt in blocks
+  const int deal = a.xcd_interleave > 0 ? a.xcd_interleave : 1;
+  const int per = (a.n_tiles + 8 * deal - 1) / (8 * deal) * deal;
   const int xcd = blockIdx.x & 7;
   const int j0 = blockIdx.x >> 3;
   const int stride = gridDim.x >> 3;
   auto tile_at = [&](int k) {
     const int j = j0 + k * stride;
-    const int t = a.xcd_interleave ? j * 8 + xcd : xcd * per + j;
+    const int g = a.xcd_interleave;
+    const int t = g ? ((j / g) * 8 + xcd) * g + j % g : xcd * per + j;
     return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
   };
   const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
@@ -768,11 +772,13 @@ static int launch_rings(const RingLaunch &L) {
   a.fout_bytes = unsigned(extents[4]);
   a.off_elems = unsigned(z[15]);
   a.off_telems = unsigned(z[16]);
-  // measured at 1e7 elements: the matrix-only launch is 6 % faster with one contiguous range per
-  // XCD (halo coordinates shared in that XCD's L2), the launches that read the source values 5-7 %
-  // faster with the tiles dealt round-robin (one front of reads across the chip)
-  a.xcd_interleave = load ? 1 : 0;
-  if (const char *v = std::getenv("TFEM_RINGS_XCD")) a.xcd_interleave = std::strcmp(v, "interleave") == 0;
+  // measured at 1e7 elements: the matrix-only launch is 4-6 % faster with one contiguous range
+  // per XCD (halo coordinates shared in that XCD's L2), the launches that read the source values
+  // 6-7 % faster with the tile list dealt to the XCDs in blocks of 4 (one front of reads across
+  // the chip; blocks of 1, 2, 8 within 1.5 %)
+  a.xcd_interleave = load ? 4 : 0;
+  if (const char *v = std::getenv("TFEM_RINGS_XCD"))  // developer switch: block size, 0 = ranges
+    a.xcd_interleave = std::strcmp(v, "interleave") == 0 ? 1 : std::atoi(v);
   if (load && (z[18] == 0 || z[17] > kRingElemPerLane * kRingBlock))
     return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan has %lld elements: the fused load "
                 "vector stages at most %d", (long long)z[17], kRingElemPerLane * kRingBlock);
@@ -824,7 +830,8 @@ static int launch_rings(const RingLaunch &L) {
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const int per = int((z[0] + 7) / 8);
+  const int deal = a.xcd_interleave > 0 ? a.xcd_interleave : 1;
+  const int per = int((z[0] + 8 * deal - 1) / (8 * deal)) * deal;
   // resident workgroups: what LDS and registers allow per CU, on every CU
   int per_cu = 0;
   hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRingBlock, lds);
