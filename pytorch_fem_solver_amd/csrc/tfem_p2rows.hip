@@ -23,6 +23,7 @@
 // contiguous piece of the CSR array whose offset is in the descriptor).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "tfem_common.hpp"
@@ -46,6 +47,7 @@ struct P2RowArgs {
   unsigned off_desc, off_rows, off_gid;
   int n_tiles;
   int lds_vert;
+  int xcd_ranges;  // 1: every XCD works on one contiguous range of the tile list, 0: tile = workgroup
   // row 0 (vertex kinds) or row 3 (edge kind) of the constant maps, alpha / beta folded in
   T ca[6], cb[6], cd[6], cm[6];
 };
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per = (a.n_tiles + 7) / 8;
-  const int tile = int(blockIdx.x & 7) * per + int(blockIdx.x >> 3);
-  if (tile >= a.n_tiles || int(blockIdx.x >> 3) >= per) return;
+  const int tile = a.xcd_ranges ? int(blockIdx.x & 7) * per + int(blockIdx.x >> 3) : int(blockIdx.x);
+  if (tile >= a.n_tiles || (a.xcd_ranges && int(blockIdx.x >> 3) >= per)) return;
   ring_const_i32 d = (ring_const_i32)(uintptr_t)(a.plan + a.off_desc + 64u * unsigned(tile));
   const int vert_off = d[0], n_vert = d[1], row_off = d[2], n_own = d[7];
   const int row0 = d[3 + wave], row1 = d[4 + wave], rs0 = d[12 + wave];
@@ -307,6 +309,8 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
     a.off_rows = unsigned(z[11 + 3 * kind]);
     a.off_gid = unsigned(z[12 + 3 * kind]);
     a.n_tiles = int(z[kind]);
+    a.xcd_ranges = 1;
+    if (const char *v = std::getenv("TFEM_P2_XCD")) a.xcd_ranges = std::strcmp(v, "interleave") != 0;
     a.lds_vert = (int(z[4 + kind]) + 1) & ~1;
     // row 0 (vertex DoF at p0) / row 3 (edge DoF (p0, p1)) of the constant maps, in T, sums in
     // quadrature order like the reference's (integrand * dx).sum(-3)
