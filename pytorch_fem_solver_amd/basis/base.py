@@ -130,7 +130,7 @@ class AbstractBasis(abc.ABC):
         if layout is None:
             layout = "dense" if n * n * vals.element_size() <= DENSE_LIMIT_BYTES else "csr"
         if layout == "csr":
-            return matrix if matrix.device == self._engine.home else matrix.to(self._engine.home)
+            return self._engine.wrap_csr_home(vals)
         if layout != "dense":
             raise ValueError(f"unknown layout {layout!r}")
         return self._engine._home(matrix.to_dense())
