@@ -88,46 +88,62 @@ class InterfaceExchange:
     def nbytes(self):
         return self.buffer.numel() * self.buffer.element_size()
 
-    def reduce(self, vals=None, f=None):
-        """Sum the shared entries of ``vals`` (local CSR values) and ``f`` (local vector,
-        any shape with N_local entries) across ranks, in place."""
-        import torch.distributed as dist
+    def _exchange_copy(self, entry, vals, f):
+        """Device side of the exchange: one launch of libtfem_hip that packs the shared
+        entries of vals / f into the buffer (``tfem_interface_pack``) or writes the summed
+        buffer back (``tfem_interface_unpack``)."""
+        from . import _native
 
         buf = self.buffer
+        lib = _native.load()
         flat_f = f.view(-1) if f is not None else None
-        if buf.is_cuda:
-            # one pack and one unpack launch of libtfem_hip around the all-reduce
-            from . import _native
+        ok = lambda t: t is None or (t.is_cuda and t.is_contiguous() and t.dtype == buf.dtype)  # noqa: E731
+        if not (ok(vals) and ok(flat_f)):
+            raise ValueError("interface exchange: vals / f must be contiguous device tensors of the buffer's dtype")
+        args = [_native.ptr(vals), _native.ptr(flat_f), buf.element_size(), _native.ptr(self.k_idx),
+                _native.ptr(self.k_pos), self.k_idx.numel(), _native.ptr(self.f_idx),
+                _native.ptr(self.f_pos), self.f_idx.numel(), _native.ptr(buf)]
+        if entry == "pack":
+            args.append(buf.numel())
+        with torch.cuda.device(buf.device):
+            args.append(_native.current_stream(buf.device))
+            _native.check(getattr(lib, "tfem_interface_" + entry)(*args))
 
-            lib = _native.load()
-            real_bytes = buf.element_size()
-            stream = _native.current_stream(buf.device)
-            ok = lambda t: t is None or (t.is_cuda and t.is_contiguous() and t.dtype == buf.dtype)  # noqa: E731
-            if not (ok(vals) and ok(flat_f)):
-                raise ValueError("interface exchange: vals / f must be contiguous device tensors of the buffer's dtype")
-            with torch.cuda.device(buf.device):
-                _native.check(lib.tfem_interface_pack(
-                    _native.ptr(vals), _native.ptr(flat_f), real_bytes, _native.ptr(self.k_idx),
-                    _native.ptr(self.k_pos), self.k_idx.numel(), _native.ptr(self.f_idx),
-                    _native.ptr(self.f_pos), self.f_idx.numel(), _native.ptr(buf), buf.numel(), stream))
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                _native.check(lib.tfem_interface_unpack(
-                    _native.ptr(vals), _native.ptr(flat_f), real_bytes, _native.ptr(self.k_idx),
-                    _native.ptr(self.k_pos), self.k_idx.numel(), _native.ptr(self.f_idx),
-                    _native.ptr(self.f_pos), self.f_idx.numel(), _native.ptr(buf), stream))
-            return vals, f
+    def pack(self, vals=None, f=None):
+        """Zero the interface buffer and copy this rank's shared entries into it."""
+        buf = self.buffer
+        if buf.is_cuda:
+            self._exchange_copy("pack", vals, f)
+            return buf
         # host tensors (the gloo tests of the exchange logic): the same copies with torch
         buf.zero_()
         if vals is not None:
             buf[self.k_pos] = vals[self.k_idx]
         if f is not None:
-            buf[self.f_pos] = flat_f[self.f_idx]
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf[self.f_pos] = f.view(-1)[self.f_idx]
+        return buf
+
+    def unpack(self, vals=None, f=None):
+        """Write the (summed) interface buffer back into vals / f, in place."""
+        buf = self.buffer
+        if buf.is_cuda:
+            self._exchange_copy("unpack", vals, f)
+            return vals, f
         if vals is not None:
             vals[self.k_idx] = buf[self.k_pos]
         if f is not None:
-            flat_f[self.f_idx] = buf[self.f_pos]
+            f.view(-1)[self.f_idx] = buf[self.f_pos]
         return vals, f
+
+    def reduce(self, vals=None, f=None):
+        """Sum the shared entries of ``vals`` (local CSR values) and ``f`` (local vector,
+        any shape with N_local entries) across ranks, in place: pack, ONE all-reduce of the
+        packed buffer, unpack."""
+        import torch.distributed as dist
+
+        self.pack(vals, f)
+        dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
+        return self.unpack(vals, f)
 
     def reduce_on(self, stream, vals=None, f=None):
         """``reduce`` enqueued on a side stream behind the work already queued on the current
