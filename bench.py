@@ -202,11 +202,28 @@ def main():
     # timed region, which ends with a device-wide synchronise)
     comm_stream = torch.cuda.Stream(device=device) if distributed else None
 
+    # N > 1: the results of step i are still being exchanged while step i+1 assembles, so the
+    # steps rotate over three preallocated (vals, f) pairs; before a pair is written again the
+    # assembly stream waits (on the device, not the host) for the exchange that last used it
+    depth = 3
+    pairs = [(torch.empty(nnz), torch.empty(n_verts)) for _ in range(depth)] if distributed else None
+    exchanged = [None] * depth
+    counter = [0]
+
+    def claim_pair():
+        if exchange is not None and exchanged[counter[0] % depth] is not None:
+            torch.cuda.current_stream().wait_event(exchanged[counter[0] % depth])
+
     def step():
-        vals, f = engine.assemble_system(1.0, 0.0, fq)  # one fused launch: K and f
-        if exchange is not None:
-            exchange.reduce_on(comm_stream, vals, f)
-        return vals, f
+        if exchange is None:
+            return engine.assemble_system(1.0, 0.0, fq)  # one fused launch: K and f
+        slot = counter[0] % depth
+        counter[0] += 1
+        vals, f = engine.assemble_system(1.0, 0.0, fq, out=pairs[slot])
+        return vals, f, slot
+
+    def exchange_step(vals, f, slot):
+        exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
 
     def barrier():
         if distributed:
@@ -214,18 +231,22 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        claim_pair()
+        out = step()
+        if exchange is not None:
+            exchange_step(*out)
     barrier()
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
+        claim_pair()
         starts[i].record()
-        vals, f = engine.assemble_system(1.0, 0.0, fq)
+        out = step()
         ends[i].record()
         if exchange is not None:
-            exchange.reduce_on(comm_stream, vals, f)
+            exchange_step(*out)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:

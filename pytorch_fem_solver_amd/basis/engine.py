@@ -558,18 +558,29 @@ class AssemblyEngine:
             )
         return self._gather_local(out) if two_pass else out
 
-    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True):
+    def _output(self, given, numel, what):
+        """A caller-provided result buffer (pipelines that rotate preallocated buffers) or a
+        fresh one; every kernel writes each entry exactly once, so nothing is cleared."""
+        if given is None:
+            return torch.empty(numel, dtype=self.dtype, device=self.device)
+        if (given.dtype != self.dtype or given.device != self.device or given.numel() != numel
+                or not given.is_contiguous()):
+            raise ValueError(f"out: {what} must be a contiguous {self.dtype} tensor of {numel} "
+                             f"entries on {self.device}")
+        return given.view(-1)
+
+    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True, out=(None, None)):
         """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass and,
         with source values fq (E, Q), the load vector (want_matrix=False: the vector alone)."""
         d = self._inputs()
         rings = self.ring_plan()
         nnz = int(self.csr_structure()[1].shape[0])
         # rows of vertices without elements are empty, every other entry is written once
-        vals = torch.empty(nnz, dtype=self.dtype, device=self.device) if want_matrix else None
+        vals = self._output(out[0], nnz, "CSR values") if want_matrix else None
         fout = None
         if fq is not None:
             fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
-            fout = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+            fout = self._output(out[1], self.n_dofs, "load vector")
         with torch.cuda.device(self.device):
             _native.check(
                 self.lib.tfem_p1_assemble_rings(
@@ -606,15 +617,21 @@ class AssemblyEngine:
             )
         return vals, fout
 
-    def assemble_system(self, alpha, beta, fq):
+    def assemble_system(self, alpha, beta, fq, out=None):
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
         values fq (E, Q): one fused launch on the ring and tile paths, two launches
-        otherwise."""
+        otherwise.  ``out=(vals, f)``: write into these preallocated device buffers."""
         if self._use_rings() and self.ring_plan()["elems_staged"]:
-            return self._assemble_rings(alpha, beta, fq)
+            return self._assemble_rings(alpha, beta, fq, out=out or (None, None))
         if self.tile_plan() is not None:
-            return self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
-        return self.bilinear(alpha, beta), self.load(fq)
+            vals, f = self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
+        else:
+            vals, f = self.bilinear(alpha, beta), self.load(fq)
+        if out is not None:  # kernels without an output argument: one device copy each
+            self._output(out[0], vals.numel(), "CSR values").copy_(vals.view(-1))
+            self._output(out[1], f.numel(), "load vector").copy_(f.view(-1))
+            return out[0], out[1]
+        return vals, f
 
     def load(self, fq):
         """(N_dof,) vector of sum_q f_q phi_i dx_q; fq is (E, Q) on any device."""

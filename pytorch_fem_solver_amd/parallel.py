@@ -145,19 +145,25 @@ class InterfaceExchange:
         dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
         return self.unpack(vals, f)
 
-    def reduce_on(self, stream, vals=None, f=None):
+    def reduce_on(self, stream, vals=None, f=None, record=True):
         """``reduce`` enqueued on a side stream behind the work already queued on the current
-        stream, so that the next (independent) assembly launch overlaps the exchange.  The
-        caller synchronises ``stream`` (or the device) before using vals / f."""
-        done = torch.cuda.Event()
-        done.record()  # everything queued so far on the current stream (the assembly kernel)
+        stream, so that the next (independent) assembly launch overlaps the exchange.
+        Returns the event that marks the end of the exchange on ``stream``: the caller waits
+        on it (``torch.cuda.current_stream().wait_event``) before it reuses or reads vals / f.
+        ``record=True`` also tells the caching allocator that ``stream`` uses the tensors;
+        callers that rotate their own preallocated buffers and wait on the event pass False."""
+        ready = torch.cuda.Event()
+        ready.record()  # everything queued so far on the current stream (the assembly kernel)
         with torch.cuda.stream(stream):
-            stream.wait_event(done)
-            for t in (vals, f):
-                if t is not None:
-                    t.record_stream(stream)
+            stream.wait_event(ready)
+            if record:
+                for t in (vals, f):
+                    if t is not None:
+                        t.record_stream(stream)
             self.reduce(vals, f)
-        return vals, f
+            done = torch.cuda.Event()
+            done.record(stream)
+        return done
 
     # ------------------------------------------------------------------ constructors
     @classmethod

@@ -397,6 +397,14 @@ def test_fused_system_launch_matches_separate_forms(order, kernel):
     assert scaled_error(vals.cpu(), orc.assemble_csr_values(local, slots, colind.shape[0])) <= TOL
     fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], order, "load")
     assert scaled_error(f.cpu().reshape(-1, 1), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
+    # preallocated result buffers (pipelines that rotate buffers, bench.py at N > 1)
+    out = (torch.full_like(vals, float("nan")), torch.full_like(f.view(-1), float("nan")))
+    vals2, f2 = basis._engine.assemble_system(1.0, 1.0, fq, out=out)
+    assert vals2.data_ptr() == out[0].data_ptr() and f2.data_ptr() == out[1].data_ptr()
+    assert torch.equal(vals2.view(-1), vals.view(-1)) or kernel == "tiles"  # LDS atomics: order varies
+    assert scaled_error(vals2.cpu(), vals.cpu()) <= 1e-14 and scaled_error(f2.cpu().view(-1), f.cpu().view(-1)) <= 1e-14
+    with pytest.raises(ValueError):
+        basis._engine.assemble_system(1.0, 1.0, fq, out=(out[0][:-1], out[1]))
     # the load-only launch and the strict-order atomic kernels agree too
     f_only = basis._engine.load(fq)
     assert scaled_error(f_only.cpu(), f.cpu()) <= 1e-14
