@@ -169,6 +169,16 @@ int tfem_csr_gather(const void *local, int real_bytes, const int64_t *gptr, cons
 int tfem_csr_spmv(const int64_t *rowptr, const int32_t *colind, const void *vals, int real_bytes,
                   int64_t n_rows, const void *x, void *y, void *stream);
 
+/* A P1 DoF vector u (n_verts entries) on both sides of every interior edge: replaces the
+ * tensor branch of Basis.interpolate(InteriorEdgesBasis, u) (reference basis.py:98-177;
+ * SURVEY 8(f) f-2).  conn: (n_elems, 3) int32 cell vertices; edge_cells: (n_edges, 2) int64
+ * = mesh["interior_edges", "cells"]; points: (n_edges, n_points, 2) = the edge basis's
+ * integration points.  value: (n_edges, 2, n_points); grad: (n_edges, 2, 2) (constant along
+ * the edge for P1).  All DEVICE pointers; ids are trusted (they come from the mesh topology). */
+int tfem_edge_interpolate_p1(const void *coords, int real_bytes, const int32_t *conn,
+                             const int64_t *edge_cells, const void *points, int64_t n_edges,
+                             int n_points, const void *u, void *value, void *grad, void *stream);
+
 /* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
 int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,

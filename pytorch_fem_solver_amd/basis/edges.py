@@ -4,8 +4,9 @@ Mirror of reference torch_fem/basis/interior_edges_basis.py and
 interior_edges_fracture_basis.py.  Only ``integration_points``, ``_dx``, ``v`` and
 ``integrate_functional`` are meaningful (the reference marks the DoF maps of these
 classes as incorrect, interior_edges_basis.py:20).  Edge integrals are O(N_edges * 2)
-work outside the assembly kernel's scope: they are torch
-expressions, as in the reference, and do not touch libtfem_hip.
+work outside the assembly kernel's scope: the bases' own data are
+torch expressions, as in the reference; evaluating a P1 DoF vector on the edges
+(``Basis.interpolate``) is one launch of libtfem_hip (``tfem_edge_interpolate_p1``).
 """
 
 from __future__ import annotations

@@ -280,6 +280,34 @@ class AssemblyEngine:
     def _stream(self):
         return _native.current_stream(self.device)
 
+    def edge_interpolate(self, edge_cells, points, u):
+        """P1 DoF vector u on both sides of the interior edges: one tfem_edge_interpolate_p1
+        launch.  edge_cells (N_e, 2) cell ids, points (N_e, Q, 2); returns value (N_e, 2, Q)
+        and gradient (N_e, 2, 2) on the compute device."""
+        if self.poly_order != 1 or self.n_fractures:
+            raise NotImplementedError("edge interpolation kernel: P1 on one 2-D mesh")
+        d = self._inputs()
+        dev = self.device
+        cells = edge_cells.to(dev, torch.int64).contiguous()
+        points = points.to(dev, self.dtype).contiguous()
+        u = u.detach().to(dev, self.dtype).reshape(-1).contiguous()
+        n_edges, n_points = int(points.shape[0]), int(points.shape[1])
+        if tuple(cells.shape) != (n_edges, 2) or points.shape[2] != 2 or u.numel() != self.coords_per_mesh:
+            raise ValueError("edge interpolation: edge_cells (N_e, 2), points (N_e, Q, 2), u (N_v,) expected")
+        if n_edges and (int(cells.min()) < 0 or int(cells.max()) >= self.n_elems):
+            raise IndexError("edge interpolation: cell id outside the mesh")
+        value = torch.empty((n_edges, 2, n_points), dtype=self.dtype, device=dev)
+        grad = torch.empty((n_edges, 2, 2), dtype=self.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(
+                self.lib.tfem_edge_interpolate_p1(
+                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
+                    _native.ptr(cells), _native.ptr(points), n_edges, n_points, _native.ptr(u),
+                    _native.ptr(value), _native.ptr(grad), self._stream(),
+                )
+            )
+        return value, grad
+
     def _home(self, tensor):
         """Result on the caller's device.  A host-resident caller gets large results through a
         pinned staging copy (pageable device-to-host copies run at ~4 GB/s on this platform)."""

@@ -79,37 +79,74 @@ class Basis(AbstractBasis):
 
     def interpolate(self, basis, tensor=None):
         """Evaluate a DoF vector (or a function of the nodes) at this basis's own
-        quadrature points or on the interior edges (basis.py:98-177).  Post-processing,
-        outside the assembly kernel: torch expressions."""
+        quadrature points or on the interior edges (basis.py:98-177).  On the interior edges
+        a P1 DoF vector goes through ONE tfem_edge_interpolate_p1 launch (SURVEY.md 8 f-2);
+        vectors that carry autograd history, and the own-points case, are torch expressions
+        on the device."""
         from .edges import InteriorEdgesBasis
 
-        if basis is self:
-            dof_ids = self._global_dofs4elements.unsqueeze(-2)
-            v, v_grad = self.v, self.v_grad
-        elif basis.__class__ == InteriorEdgesBasis:
-            edge_mesh = basis.mesh
-            cell_pairs = edge_mesh["interior_edges", "cells"]
-            gather = edge_mesh.compute_coordinates_4_cells
-            dof_ids = gather(edge_mesh["cells", "vertices"], cell_pairs).unsqueeze(-2)
-            origin = gather(self.mesh["cells", "coordinates"][..., [0], :], cell_pairs).unsqueeze(-3)
-            inv_jac = gather(self._inv_map_jacobian, cell_pairs)
-            edge_points = basis.integration_points.unsqueeze(-3)
-            local_points = self._element.compute_inverse_map(origin, edge_points, inv_jac)
-            bar = self._element.compute_barycentric_coordinates(local_points.squeeze(-3))
-            v, v_grad = self._element.compute_shape_functions(bar, inv_jac)
-        else:
+        on_edges = basis.__class__ == InteriorEdgesBasis
+        if basis is not self and not on_edges:
             raise NotImplementedError("Interpolation for this basis not implemented")
 
+        def is_dof_vector(t):
+            n = self._basis_parameters["nb_dofs"]
+            return (torch.is_tensor(t) and not t.requires_grad and t.dtype == self._engine.dtype
+                    and tuple(t.shape) == (n, 1))
+
+        def edge_kernel(values):
+            pts = basis.integration_points
+            n_edges, n_points = pts.shape[0], pts.shape[-2]
+            val, grad = self._engine.edge_interpolate(
+                basis.mesh["interior_edges", "cells"], pts.reshape(n_edges, n_points, 2), values)
+            home = values.device
+            return (val.reshape(n_edges, 2, n_points, 1, 1).to(home),
+                    grad.reshape(n_edges, 2, 1, 1, 2).to(home))
+
+        kernel_ok = on_edges and self._element.polynomial_order == 1
+        if kernel_ok and tensor is not None and is_dof_vector(tensor):
+            return edge_kernel(tensor)
+
+        lazy = {}
+
+        def shape_values():
+            """(dof ids, v, v_grad) of the torch-expression path, built on first use."""
+            if not lazy:
+                if basis is self:
+                    lazy["ids"] = self._global_dofs4elements.unsqueeze(-2)
+                    lazy["v"], lazy["v_grad"] = self.v, self.v_grad
+                else:
+                    edge_mesh = basis.mesh
+                    cell_pairs = edge_mesh["interior_edges", "cells"]
+                    gather = edge_mesh.compute_coordinates_4_cells
+                    lazy["ids"] = gather(edge_mesh["cells", "vertices"], cell_pairs).unsqueeze(-2)
+                    origin = gather(self.mesh["cells", "coordinates"][..., [0], :], cell_pairs).unsqueeze(-3)
+                    inv_jac = gather(self._inv_map_jacobian, cell_pairs)
+                    edge_points = basis.integration_points.unsqueeze(-3)
+                    local_points = self._element.compute_inverse_map(origin, edge_points, inv_jac)
+                    bar = self._element.compute_barycentric_coordinates(local_points.squeeze(-3))
+                    lazy["v"], lazy["v_grad"] = self._element.compute_shape_functions(bar, inv_jac)
+            return lazy["ids"], lazy["v"], lazy["v_grad"]
+
         if tensor is not None:
+            dof_ids, v, v_grad = shape_values()
             nodal = tensor[dof_ids]
             return (nodal * v).sum(-2, keepdim=True), (nodal * v_grad).sum(-2, keepdim=True)
 
         nodes = self._coords4global_dofs
 
         def interpolator(function):
-            return (function(nodes)[dof_ids] * v).sum(-2, keepdim=True)
+            values = function(nodes)
+            if kernel_ok and is_dof_vector(values):
+                return edge_kernel(values)[0]
+            dof_ids, v, _ = shape_values()
+            return (values[dof_ids] * v).sum(-2, keepdim=True)
 
         def interpolator_grad(function):
-            return (function(nodes)[dof_ids] * v_grad).sum(-2, keepdim=True)
+            values = function(nodes)
+            if kernel_ok and is_dof_vector(values):
+                return edge_kernel(values)[1]
+            dof_ids, _, v_grad = shape_values()
+            return (values[dof_ids] * v_grad).sum(-2, keepdim=True)
 
         return interpolator, interpolator_grad

@@ -624,6 +624,37 @@ __global__ __launch_bounds__(kBlock) void k_csr_spmv(const int64_t *rowptr, cons
   if (row < n_rows && sub == 0) y[row] = acc;
 }
 
+// P1 field on the two sides of every interior edge (Basis.interpolate(InteriorEdgesBasis, u),
+// reference basis.py:98-177 with the tensor argument): one lane per (edge, side).  The lane
+// rebuilds the side's affine map from the three vertices (element_tri.py:132-145), pulls the
+// edge's quadrature points back with (x - x0) J^-T (abstract_element.py:18-26), evaluates the
+// barycentric shape functions there and contracts with the three nodal values; the gradient
+// is constant along the edge.  No intermediate (N_e, 2, Q, 3, .) tensors reach HBM.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_edge_interpolate_p1(
+    const T *coords, const int32_t *conn, const int64_t *edge_cells, const T *points, const T *u,
+    int64_t n_sides, int n_points, T *value, T *grad) {
+  const int64_t side = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (side >= n_sides) return;
+  const int64_t cell = edge_cells[side];
+  const int32_t v0 = conn[3 * cell], v1 = conn[3 * cell + 1], v2 = conn[3 * cell + 2];
+  const T x0 = coords[2 * int64_t(v0)], y0 = coords[2 * int64_t(v0) + 1];
+  const T a = coords[2 * int64_t(v1)] - x0, c = coords[2 * int64_t(v1) + 1] - y0;
+  const T b = coords[2 * int64_t(v2)] - x0, d = coords[2 * int64_t(v2) + 1] - y0;
+  const T inv_det = T(1) / (a * d - b * c);
+  const T i00 = inv_det * d, i01 = inv_det * (-b), i10 = inv_det * (-c), i11 = inv_det * a;
+  const T u0 = u[v0], u1 = u[v1], u2 = u[v2];
+  // rows of barycentric_grad @ J^-1: (-i0 - i1, i0, i1)
+  grad[2 * side] = u0 * (-i00 - i10) + u1 * i00 + u2 * i10;
+  grad[2 * side + 1] = u0 * (-i01 - i11) + u1 * i01 + u2 * i11;
+  const T *pts = points + (side >> 1) * int64_t(2 * n_points);
+  for (int q = 0; q < n_points; ++q) {
+    const T dx = pts[2 * q] - x0, dy = pts[2 * q + 1] - y0;
+    const T xi = dx * i00 + dy * i01, eta = dx * i10 + dy * i11;
+    value[side * n_points + q] = u0 * (T(1) - xi - eta) + u1 * xi + u2 * eta;
+  }
+}
+
 // Interface exchange of the element-range sharding (parallel.py): entries of the local CSR
 // values / local vector that belong to DoFs shared with another rank are copied into the
 // packed buffer the ranks all-reduce (pack) and back (unpack).  One launch each.
@@ -820,6 +851,30 @@ int tfem_csr_spmv(const int64_t *rowptr, const int32_t *colind, const void *vals
     hipLaunchKernelGGL(k_csr_spmv<float>, dim3(blocks_for(8 * n_rows)), dim3(kBlock), 0, s, rowptr, colind,
                        static_cast<const float *>(vals), static_cast<const float *>(x),
                        static_cast<float *>(y), n_rows);
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_edge_interpolate_p1(const void *coords, int real_bytes, const int32_t *conn,
+                             const int64_t *edge_cells, const void *points, int64_t n_edges,
+                             int n_points, const void *u, void *value, void *grad, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (n_edges < 0 || n_points < 0) return fail(TFEM_ERR_INVALID_ARGUMENT, "negative size");
+  if (n_edges == 0) return TFEM_OK;
+  if (!coords || !conn || !edge_cells || !u || !value || !grad || (n_points > 0 && !points))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n_sides = 2 * n_edges;
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_edge_interpolate_p1<double>, dim3(blocks_for(n_sides)), dim3(kBlock), 0, s,
+                       static_cast<const double *>(coords), conn, edge_cells,
+                       static_cast<const double *>(points), static_cast<const double *>(u), n_sides,
+                       n_points, static_cast<double *>(value), static_cast<double *>(grad));
+  else
+    hipLaunchKernelGGL(k_edge_interpolate_p1<float>, dim3(blocks_for(n_sides)), dim3(kBlock), 0, s,
+                       static_cast<const float *>(coords), conn, edge_cells,
+                       static_cast<const float *>(points), static_cast<const float *>(u), n_sides,
+                       n_points, static_cast<float *>(value), static_cast<float *>(grad));
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

@@ -276,6 +276,42 @@ def test_interior_edges_basis_and_interpolation():
     assert scaled_error(grad.cpu(), d["out_interp_edges_grad"]) <= 1e-11
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_edge_interpolation_kernel_against_the_torch_expressions(dtype):
+    """tfem_edge_interpolate_p1 (the tensor branch of Basis.interpolate on interior edges,
+    basis.py:98-177) against the reference's expression sequence evaluated by torch -- the
+    path a vector with autograd history takes -- on a jittered and a Delaunay mesh."""
+    from pytorch_fem_solver_amd import meshgen
+
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for mesh_np in (meshgen.unit_square(40, 0.25, 3), meshgen.delaunay_square(3000, seed=2)):
+        mesh_np = dict(mesh_np, vertices=mesh_np["vertices"].astype(np.float64 if dtype == torch.float64 else np.float32))
+        # without "neighbors" the edge -> cells table is matched edge by edge; with it the
+        # reference pairs the SORTED cell pairs with the edge list (abstract_mesh.py:207-230,
+        # SURVEY.md appendix C-3; the golden fixture of the test above pins that behaviour)
+        mesh_np.pop("neighbors", None)
+        mesh = tf().MeshTri(triangulation=mesh_np)
+        basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+        edge_basis = tf().InteriorEdgesBasis(mesh, tf().ElementLine(1, 2))
+        n_edges = edge_basis.integration_points.shape[0]
+        n_points = edge_basis.integration_points.shape[-2]
+        xy = torch.as_tensor(mesh_np["vertices"], dtype=dtype)
+        u = (torch.sin(3 * xy[:, :1]) * torch.cos(2 * xy[:, 1:]) + xy[:, :1] ** 2).to(dtype)
+        val, grad = basis.interpolate(edge_basis, u)
+        assert val.shape == (n_edges, 2, n_points, 1, 1) and grad.shape == (n_edges, 2, 1, 1, 2)
+        want_val, want_grad = basis.interpolate(edge_basis, u.clone().requires_grad_(True))
+        assert want_val.shape == val.shape and want_grad.shape == grad.shape
+        assert scaled_error(val.cpu(), want_val.detach().cpu()) <= tol
+        assert scaled_error(grad.cpu(), want_grad.detach().cpu()) <= tol
+        # a P1 field is continuous: both sides agree on the edge; the tangential derivative too
+        assert (val[:, 0] - val[:, 1]).abs().max().item() <= 50 * tol * val.abs().max().item()
+        # the closures of the function branch reach the same launch
+        interp, interp_grad = basis.interpolate(edge_basis)
+        field = lambda nodes: torch.sin(3 * nodes[:, :1]) * torch.cos(2 * nodes[:, 1:]) + nodes[:, :1] ** 2  # noqa: E731
+        assert scaled_error(interp(field).cpu(), val.cpu()) <= 10 * tol
+        assert scaled_error(interp_grad(field).cpu(), grad.cpu()) <= 10 * tol
+
+
 # ---------------------------------------------------------------------------------------
 # oracle comparisons on seeded meshes + size-independent properties at full size
 # ---------------------------------------------------------------------------------------
