@@ -313,6 +313,11 @@ def main():
                 },
             },
         }
+        # what the HBM interface moved (PMC bytes of profiles/) over the live launch duration
+        for obj, ms in ((line["roofline"], k_ms), (line["roofline"]["stiffness_only"], k_only_ms)):
+            if obj["traffic"]:
+                obj["traffic_GBps"] = obj["traffic"] / (ms * 1e-3) / 1e9
+                obj["traffic_frac_of_peak"] = obj["traffic_GBps"] / HBM_PEAK_GBS
         if world == 1 and not args.no_other_configs:
             line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3(device)}
         if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
