@@ -69,6 +69,11 @@ __device__ __forceinline__ unsigned long long ring_stamp() {
   return t;
 }
 
+#ifndef TFEM_RING_BAND
+#define TFEM_RING_BAND 11
+#endif
+constexpr int kRingBand = TFEM_RING_BAND;  // short slot loop of the 15-slot kernels (0: none)
+
 // Field accessors of a row record (bit layout: tfem_rings_host.cpp).
 template <int SLOTS>
 struct RingRec {
@@ -99,7 +104,9 @@ struct RingRec {
 // that closes the fan (i + 1 == k) the second one belongs to slot 0 and is moved there at the
 // end (slots i >= k carry flag 0 and contribute nothing).  No branches: the reciprocal chains
 // of the slots interleave.
-template <typename T, int SLOTS, bool MASS, bool DETS>
+// NIT < SLOTS: the caller knows that no row of the wave has more than NIT neighbours (the
+// 15-slot records of unstructured meshes: 11 slots cover ~94 % of the waves of a Delaunay mesh).
+template <typename T, int SLOTS, bool MASS, bool DETS, int NIT = SLOTS>
 __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLOTS> &rec,
                                          uint32_t lv, const T *xy, T (&off)[SLOTS + 1], T &diag,
                                          T (&sdets)[SLOTS]) {
@@ -113,8 +120,12 @@ __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLO
   T dsum = T(0);  // sum of the signed determinants around the vertex (mass part)
 #pragma unroll
   for (int i = 0; i <= SLOTS; ++i) off[i] = T(0);
+  if (DETS) {
 #pragma unroll
-  for (int i = 0; i < SLOTS; ++i) {
+    for (int i = NIT; i < SLOTS; ++i) sdets[i] = T(0);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
     // neighbour behind slot i: slot i + 1, or slot 0 where the fan closes
     const uint32_t idn = (i + 1 < SLOTS && i + 1 != k) ? rec.id(i + 1 < SLOTS ? i + 1 : 0) : id0;
     lds_xy(xy, idn, px, py);
@@ -568,8 +579,13 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
     T off[SLOTS + 1], diag, sdets[SLOTS];
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
-      ring_row<T, SLOTS, MASS, LOAD>(a, rec, unsigned(my_row < dc.row1 ? my_row : 0),
-                                     xy + cur * 2 * a.lds_vert, off, diag, sdets);
+      const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
+      // wave-uniform: a shorter slot loop when no row of this wave needs the long one
+      if (SLOTS > kRingBand && kRingBand > 0 && __builtin_amdgcn_ballot_w64(rec.k() > kRingBand) == 0)
+        ring_row<T, SLOTS, MASS, LOAD, (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : SLOTS>(
+            a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
+      else
+        ring_row<T, SLOTS, MASS, LOAD>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
     } else {
       diag = T(1);
 #pragma unroll
