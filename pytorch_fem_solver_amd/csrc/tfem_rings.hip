@@ -178,7 +178,7 @@ constexpr int ring_stage_entries() { return 64 * (SLOTS + 1) + 2; }
 
 // Row entries -> the wave's stage (plain LDS stores).  `pre` = stage index of this lane's row;
 // returns the number of entries the wave staged (uniform).
-template <typename T, int SLOTS>
+template <typename T, int SLOTS, int NIT = SLOTS>
 __device__ __forceinline__ int ring_stage(const RingRec<SLOTS> &rec, const T (&off)[SLOTS + 1], T diag,
                                           T *stage, int &pre) {
   const int k = rec.k();
@@ -187,7 +187,7 @@ __device__ __forceinline__ int ring_stage(const RingRec<SLOTS> &rec, const T (&o
   pre = incl - len;
   constexpr int kSpare = 64 * (SLOTS + 1);
 #pragma unroll
-  for (int i = 0; i < SLOTS; ++i) stage[i < k ? pre + rec.pos(i) : kSpare] = off[i];
+  for (int i = 0; i < NIT; ++i) stage[i < k ? pre + rec.pos(i) : kSpare] = off[i];
   stage[k > 0 ? pre + rec.dpos() : kSpare] = diag;
   return __builtin_amdgcn_readlane(incl, 63);
 }
@@ -206,11 +206,17 @@ __device__ __forceinline__ void ring_store_run1(const T *stage, int total, int d
   T va[kSteps][2];
 #pragma unroll
   for (int u = 0; u < kSteps; ++u) {
+    // 15-slot stage: rows hold ~7 of 16 entries, the steps behind `total` are skipped (uniform)
+    if (SLOTS > 7 && u >= 2 && 128 * u >= total) {
+      va[u][0] = va[u][1] = T(0);
+      continue;
+    }
     va[u][0] = stage[128 * u + 2 * lane];
     va[u][1] = stage[128 * u + 2 * lane + 1];
   }
 #pragma unroll
   for (int u = 0; u < kSteps; ++u) {
+    if (SLOTS > 7 && u >= 2 && 128 * u >= total) continue;
     const int s0 = 128 * u + 2 * lane;
     const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
     const T v0 = va[u][0], v1 = va[u][1];
@@ -577,13 +583,14 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
     if (timing) t1 = ring_stamp();
     // ---- B ----
     T off[SLOTS + 1], diag, sdets[SLOTS];
+    // wave-uniform: shorter slot loops when no row of this wave needs the long ones
+    constexpr int kBandSlots = (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : SLOTS;
+    const bool banded = kBandSlots < SLOTS && __builtin_amdgcn_ballot_w64(rec.k() > kBandSlots) == 0;
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
       const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
-      // wave-uniform: a shorter slot loop when no row of this wave needs the long one
-      if (SLOTS > kRingBand && kRingBand > 0 && __builtin_amdgcn_ballot_w64(rec.k() > kRingBand) == 0)
-        ring_row<T, SLOTS, MASS, LOAD, (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : SLOTS>(
-            a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
+      if (banded)
+        ring_row<T, SLOTS, MASS, LOAD, kBandSlots>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
       else
         ring_row<T, SLOTS, MASS, LOAD>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
     } else {
@@ -596,7 +603,9 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       t2 = ring_stamp();
     }
     int total = 0, pre = 0;
-    if (KMAT && !(DBG && (a.flags & 8))) total = ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+    if (KMAT && !(DBG && (a.flags & 8)))
+      total = banded ? ring_stage<T, SLOTS, kBandSlots>(rec, off, diag, my_stage, pre)
+                     : ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
     T facc = T(0);
     if (LOAD) {
       const T *g = gtab;
