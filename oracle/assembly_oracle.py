@@ -124,6 +124,35 @@ def shape_functions(polynomial_order, bar_coords, inv_map_jacobian):
 
 
 # --------------------------------------------------------------------------- #
+# P1 field on the two sides of the interior edges (torch_fem/basis/basis.py:98-177)
+# --------------------------------------------------------------------------- #
+
+
+def edge_interpolate_p1(vertices, triangles, edge_cells, edge_points, nodal):
+    """Tensor branch of ``Basis.interpolate(InteriorEdgesBasis, u)``, basis.py:110-160.
+
+    edge_cells (N_e, 2) cell ids, edge_points (N_e, 1, Q, 2) = the edge basis's integration
+    points, nodal (N_v, 1).  Returns value (N_e, 2, Q, 1, 1) and gradient (N_e, 2, 1, 1, 2):
+    origin = first vertex of the cell (:122-124), pull-back (x - x0) J^-T
+    (abstract_element.py:18-26), barycentric shape functions and G J^-1 (element_tri.py:28-41),
+    contraction with the three nodal values (:150-158).
+    """
+    vertices = np.asarray(vertices)
+    tri = np.asarray(triangles, dtype=np.int64)
+    cells = np.asarray(edge_cells, dtype=np.int64)
+    cell_xy = vertices[tri]  # (N_T, 3, 2)
+    _, inv = det_and_inverse(jacobian_map(cell_xy))  # (N_T, 1, 2, 2)
+    inv_side = inv[cells]  # (N_e, 2, 1, 2, 2)
+    origin = cell_xy[:, [0], :][cells][:, :, None]  # (N_e, 2, 1, 1, 2)
+    points = np.asarray(edge_points)[:, None]  # (N_e, 1, 1, Q, 2)
+    local = (points - origin) @ np.swapaxes(inv_side, -1, -2)  # (N_e, 2, 1, Q, 2)
+    bar = barycentric_coordinates(local[:, :, 0])  # (N_e, 2, Q, 3, 1)
+    v, v_grad = shape_functions(1, bar, inv_side)  # (N_e, 2, Q, 3, 1), (N_e, 2, 1, 3, 2)
+    u = np.asarray(nodal).reshape(-1, 1)[tri[cells]][:, :, None]  # (N_e, 2, 1, 3, 1)
+    return (u * v).sum(-2, keepdims=True), (u * v_grad).sum(-2, keepdims=True)
+
+
+# --------------------------------------------------------------------------- #
 # geometry cache (torch_fem/basis/abstract_basis.py:42-63, basis.py:87-96)
 # --------------------------------------------------------------------------- #
 

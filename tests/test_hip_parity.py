@@ -303,6 +303,11 @@ def test_edge_interpolation_kernel_against_the_torch_expressions(dtype):
         assert want_val.shape == val.shape and want_grad.shape == grad.shape
         assert scaled_error(val.cpu(), want_val.detach().cpu()) <= tol
         assert scaled_error(grad.cpu(), want_grad.detach().cpu()) <= tol
+        if dtype == torch.float64:  # and against the numpy oracle (pinned by the reference's fixture)
+            o_val, o_grad = orc.edge_interpolate_p1(
+                mesh_np["vertices"], mesh_np["triangles"], mesh["interior_edges", "cells"].cpu().numpy(),
+                edge_basis.integration_points.cpu().numpy(), u.cpu().numpy())
+            assert scaled_error(val.cpu(), o_val) <= tol and scaled_error(grad.cpu(), o_grad) <= tol
         # a P1 field is continuous: both sides agree on the edge; the tangential derivative too
         assert (val[:, 0] - val[:, 1]).abs().max().item() <= 50 * tol * val.abs().max().item()
         # the closures of the function branch reach the same launch

@@ -136,6 +136,18 @@ def test_fracture_geometry_and_assembly(fixture):
     assert scaled_error(orc.assemble_dense_bilinear(k, conn, n), d["out_A"]) <= TOL
 
 
+def test_edge_interpolation_restatement():
+    """oracle.edge_interpolate_p1 against the reference's Basis.interpolate(InteriorEdgesBasis, u)
+    output (make_golden.py), with the reference's own edge -> cells table and edge points."""
+    d = load_golden("mesh_topology_n4.npz")
+    val, grad = orc.edge_interpolate_p1(
+        d["in_vertices"], d["in_triangles"], d["out_interior_edges_cells"],
+        d["out_edge_integration_points"], d["in_vertex_field"])
+    assert val.shape == d["out_interp_edges_val"].shape and grad.shape == d["out_interp_edges_grad"].shape
+    assert scaled_error(val, d["out_interp_edges_val"]) <= TOL
+    assert scaled_error(grad, d["out_interp_edges_grad"]) <= TOL
+
+
 def test_c_oracle_matches_numpy_oracle_and_golden():
     """oracle/assembly_oracle.c (OpenMP; CPU baseline of bench.py) against the numpy oracle
     and the reference's own outputs."""
