@@ -179,6 +179,16 @@ int tfem_edge_interpolate_p1(const void *coords, int real_bytes, const int32_t *
                              const int64_t *edge_cells, const void *points, int64_t n_edges,
                              int n_points, const void *u, void *value, void *grad, void *stream);
 
+/* Adjoint of tfem_edge_interpolate_p1 in u: grad_u (n_verts entries, overwritten) =
+ * A^T g_value + B^T g_grad for value = A u, grad = B u; g_value (n_edges, 2, n_points) and
+ * g_grad (n_edges, 2, 2) are the cotangents of the two outputs.  What autograd derives from the
+ * reference's expressions (basis.py:150-158) when u carries history; floating-point atomics, the
+ * summation order is not fixed. */
+int tfem_edge_interpolate_p1_backward(const void *coords, int real_bytes, const int32_t *conn,
+                                      const int64_t *edge_cells, const void *points, int64_t n_edges,
+                                      int n_points, const void *g_value, const void *g_grad,
+                                      void *grad_u, int64_t n_verts, void *stream);
+
 /* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
 int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,

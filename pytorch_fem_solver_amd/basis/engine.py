@@ -280,22 +280,29 @@ class AssemblyEngine:
     def _stream(self):
         return _native.current_stream(self.device)
 
+    def _edge_inputs(self, edge_cells, points):
+        if self.poly_order != 1 or self.n_fractures:
+            raise NotImplementedError("edge interpolation kernel: P1 on one 2-D mesh")
+        dev = self.device
+        cells = edge_cells.to(dev, torch.int64).contiguous()
+        points = points.detach().to(dev, self.dtype).contiguous()
+        n_edges, n_points = int(points.shape[0]), int(points.shape[1])
+        if tuple(cells.shape) != (n_edges, 2) or points.dim() != 3 or points.shape[2] != 2:
+            raise ValueError("edge interpolation: edge_cells (N_e, 2) and points (N_e, Q, 2) expected")
+        if n_edges and (int(cells.min()) < 0 or int(cells.max()) >= self.n_elems):
+            raise IndexError("edge interpolation: cell id outside the mesh")
+        return cells, points, n_edges, n_points
+
     def edge_interpolate(self, edge_cells, points, u):
         """P1 DoF vector u on both sides of the interior edges: one tfem_edge_interpolate_p1
         launch.  edge_cells (N_e, 2) cell ids, points (N_e, Q, 2); returns value (N_e, 2, Q)
         and gradient (N_e, 2, 2) on the compute device."""
-        if self.poly_order != 1 or self.n_fractures:
-            raise NotImplementedError("edge interpolation kernel: P1 on one 2-D mesh")
         d = self._inputs()
+        cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
         dev = self.device
-        cells = edge_cells.to(dev, torch.int64).contiguous()
-        points = points.to(dev, self.dtype).contiguous()
         u = u.detach().to(dev, self.dtype).reshape(-1).contiguous()
-        n_edges, n_points = int(points.shape[0]), int(points.shape[1])
-        if tuple(cells.shape) != (n_edges, 2) or points.shape[2] != 2 or u.numel() != self.coords_per_mesh:
-            raise ValueError("edge interpolation: edge_cells (N_e, 2), points (N_e, Q, 2), u (N_v,) expected")
-        if n_edges and (int(cells.min()) < 0 or int(cells.max()) >= self.n_elems):
-            raise IndexError("edge interpolation: cell id outside the mesh")
+        if u.numel() != self.coords_per_mesh:
+            raise ValueError("edge interpolation: u must hold one value per vertex")
         value = torch.empty((n_edges, 2, n_points), dtype=self.dtype, device=dev)
         grad = torch.empty((n_edges, 2, 2), dtype=self.dtype, device=dev)
         with torch.cuda.device(dev):
@@ -307,6 +314,25 @@ class AssemblyEngine:
                 )
             )
         return value, grad
+
+    def edge_interpolate_backward(self, edge_cells, points, g_value, g_grad):
+        """Adjoint of edge_interpolate in u: (N_v,) on the compute device from the cotangents
+        g_value (N_e, 2, Q) and g_grad (N_e, 2, 2); one tfem_edge_interpolate_p1_backward launch."""
+        d = self._inputs()
+        cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
+        dev = self.device
+        g_value = g_value.detach().to(dev, self.dtype).reshape(n_edges, 2, n_points).contiguous()
+        g_grad = g_grad.detach().to(dev, self.dtype).reshape(n_edges, 2, 2).contiguous()
+        grad_u = torch.empty(self.coords_per_mesh, dtype=self.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(
+                self.lib.tfem_edge_interpolate_p1_backward(
+                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
+                    _native.ptr(cells), _native.ptr(points), n_edges, n_points, _native.ptr(g_value),
+                    _native.ptr(g_grad), _native.ptr(grad_u), self.coords_per_mesh, self._stream(),
+                )
+            )
+        return grad_u
 
     def _home(self, tensor):
         """Result on the caller's device.  A host-resident caller gets large results through a

@@ -15,7 +15,28 @@ from .base import AbstractBasis, LazyIndexDict
 from .engine import AssemblyEngine
 
 
+class _EdgeInterpolateFunction(torch.autograd.Function):
+    """tfem_edge_interpolate_p1 with its adjoint in the nodal values (jump terms inside a
+    training loss; the reference gets the same derivative from autograd on basis.py:150-158)."""
+
+    @staticmethod
+    def forward(ctx, u, engine, edge_cells, points):
+        ctx.engine, ctx.edge_cells, ctx.points = engine, edge_cells, points
+        ctx.u_shape, ctx.u_device = u.shape, u.device
+        value, grad = engine.edge_interpolate(edge_cells, points, u)
+        return value.to(u.device), grad.to(u.device)
+
+    @staticmethod
+    def backward(ctx, g_value, g_grad):
+        grad_u = ctx.engine.edge_interpolate_backward(ctx.edge_cells, ctx.points, g_value, g_grad)
+        return grad_u.reshape(ctx.u_shape).to(ctx.u_device), None, None, None
+
+
 class Basis(AbstractBasis):
+    #: False: Basis.interpolate on interior edges evaluates the reference's expression sequence
+    #: with torch instead of launching tfem_edge_interpolate_p1 (the tests compare the two)
+    edge_kernel = True
+
     def _compute_dofs(self, mesh, element):
         if element.polynomial_order == 1:
             coords = mesh["vertices", "coordinates"]
@@ -80,9 +101,9 @@ class Basis(AbstractBasis):
     def interpolate(self, basis, tensor=None):
         """Evaluate a DoF vector (or a function of the nodes) at this basis's own
         quadrature points or on the interior edges (basis.py:98-177).  On the interior edges
-        a P1 DoF vector goes through ONE tfem_edge_interpolate_p1 launch (SURVEY.md 8 f-2);
-        vectors that carry autograd history, and the own-points case, are torch expressions
-        on the device."""
+        a P1 DoF vector goes through ONE tfem_edge_interpolate_p1 launch,
+        differentiable in the vector (tfem_edge_interpolate_p1_backward); the own-points case
+        is a torch expression on the device."""
         from .edges import InteriorEdgesBasis
 
         on_edges = basis.__class__ == InteriorEdgesBasis
@@ -91,19 +112,17 @@ class Basis(AbstractBasis):
 
         def is_dof_vector(t):
             n = self._basis_parameters["nb_dofs"]
-            return (torch.is_tensor(t) and not t.requires_grad and t.dtype == self._engine.dtype
-                    and tuple(t.shape) == (n, 1))
+            return torch.is_tensor(t) and t.dtype == self._engine.dtype and tuple(t.shape) == (n, 1)
 
         def edge_kernel(values):
             pts = basis.integration_points
             n_edges, n_points = pts.shape[0], pts.shape[-2]
-            val, grad = self._engine.edge_interpolate(
-                basis.mesh["interior_edges", "cells"], pts.reshape(n_edges, n_points, 2), values)
-            home = values.device
-            return (val.reshape(n_edges, 2, n_points, 1, 1).to(home),
-                    grad.reshape(n_edges, 2, 1, 1, 2).to(home))
+            val, grad = _EdgeInterpolateFunction.apply(
+                values, self._engine, basis.mesh["interior_edges", "cells"],
+                pts.detach().reshape(n_edges, n_points, 2))
+            return val.reshape(n_edges, 2, n_points, 1, 1), grad.reshape(n_edges, 2, 1, 1, 2)
 
-        kernel_ok = on_edges and self._element.polynomial_order == 1
+        kernel_ok = self.edge_kernel and on_edges and self._element.polynomial_order == 1
         if kernel_ok and tensor is not None and is_dof_vector(tensor):
             return edge_kernel(tensor)
 

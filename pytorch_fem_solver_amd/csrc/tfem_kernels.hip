@@ -655,6 +655,41 @@ __global__ __launch_bounds__(kBlock) void k_edge_interpolate_p1(
   }
 }
 
+// Adjoint of k_edge_interpolate_p1 with respect to the nodal values (training loops that
+// differentiate jump terms): per (edge, side) the three weights of the value at every point and
+// of the constant gradient, times the incoming cotangents, added to grad_u with hardware
+// floating-point atomics (grad_u zeroed by the caller; summation order is not fixed).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_edge_interpolate_p1_backward(
+    const T *coords, const int32_t *conn, const int64_t *edge_cells, const T *points,
+    const T *g_value, const T *g_grad, int64_t n_sides, int n_points, T *grad_u) {
+  const int64_t side = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (side >= n_sides) return;
+  const int64_t cell = edge_cells[side];
+  const int32_t v0 = conn[3 * cell], v1 = conn[3 * cell + 1], v2 = conn[3 * cell + 2];
+  const T x0 = coords[2 * int64_t(v0)], y0 = coords[2 * int64_t(v0) + 1];
+  const T a = coords[2 * int64_t(v1)] - x0, c = coords[2 * int64_t(v1) + 1] - y0;
+  const T b = coords[2 * int64_t(v2)] - x0, d = coords[2 * int64_t(v2) + 1] - y0;
+  const T inv_det = T(1) / (a * d - b * c);
+  const T i00 = inv_det * d, i01 = inv_det * (-b), i10 = inv_det * (-c), i11 = inv_det * a;
+  const T gx = g_grad[2 * side], gy = g_grad[2 * side + 1];
+  T w0 = gx * (-i00 - i10) + gy * (-i01 - i11);
+  T w1 = gx * i00 + gy * i01;
+  T w2 = gx * i10 + gy * i11;
+  const T *pts = points + (side >> 1) * int64_t(2 * n_points);
+  for (int q = 0; q < n_points; ++q) {
+    const T dx = pts[2 * q] - x0, dy = pts[2 * q + 1] - y0;
+    const T xi = dx * i00 + dy * i01, eta = dx * i10 + dy * i11;
+    const T gv = g_value[side * n_points + q];
+    w0 = w0 + gv * (T(1) - xi - eta);
+    w1 = w1 + gv * xi;
+    w2 = w2 + gv * eta;
+  }
+  atomicAdd(grad_u + v0, w0);
+  atomicAdd(grad_u + v1, w1);
+  atomicAdd(grad_u + v2, w2);
+}
+
 // Interface exchange of the element-range sharding (parallel.py): entries of the local CSR
 // values / local vector that belong to DoFs shared with another rank are copied into the
 // packed buffer the ranks all-reduce (pack) and back (unpack).  One launch each.
@@ -875,6 +910,34 @@ int tfem_edge_interpolate_p1(const void *coords, int real_bytes, const int32_t *
                        static_cast<const float *>(coords), conn, edge_cells,
                        static_cast<const float *>(points), static_cast<const float *>(u), n_sides,
                        n_points, static_cast<float *>(value), static_cast<float *>(grad));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_edge_interpolate_p1_backward(const void *coords, int real_bytes, const int32_t *conn,
+                                      const int64_t *edge_cells, const void *points, int64_t n_edges,
+                                      int n_points, const void *g_value, const void *g_grad,
+                                      void *grad_u, int64_t n_verts, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (n_edges < 0 || n_points < 0 || n_verts < 0) return fail(TFEM_ERR_INVALID_ARGUMENT, "negative size");
+  if (n_verts == 0) return TFEM_OK;
+  if (!grad_u) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TFEM_HIP_CHECK(hipMemsetAsync(grad_u, 0, size_t(n_verts) * size_t(real_bytes), s));
+  if (n_edges == 0) return TFEM_OK;
+  if (!coords || !conn || !edge_cells || !g_value || !g_grad || (n_points > 0 && !points))
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const int64_t n_sides = 2 * n_edges;
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_edge_interpolate_p1_backward<double>, dim3(blocks_for(n_sides)), dim3(kBlock), 0, s,
+                       static_cast<const double *>(coords), conn, edge_cells,
+                       static_cast<const double *>(points), static_cast<const double *>(g_value),
+                       static_cast<const double *>(g_grad), n_sides, n_points, static_cast<double *>(grad_u));
+  else
+    hipLaunchKernelGGL(k_edge_interpolate_p1_backward<float>, dim3(blocks_for(n_sides)), dim3(kBlock), 0, s,
+                       static_cast<const float *>(coords), conn, edge_cells,
+                       static_cast<const float *>(points), static_cast<const float *>(g_value),
+                       static_cast<const float *>(g_grad), n_sides, n_points, static_cast<float *>(grad_u));
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

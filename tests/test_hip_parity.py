@@ -299,10 +299,23 @@ def test_edge_interpolation_kernel_against_the_torch_expressions(dtype):
         u = (torch.sin(3 * xy[:, :1]) * torch.cos(2 * xy[:, 1:]) + xy[:, :1] ** 2).to(dtype)
         val, grad = basis.interpolate(edge_basis, u)
         assert val.shape == (n_edges, 2, n_points, 1, 1) and grad.shape == (n_edges, 2, 1, 1, 2)
-        want_val, want_grad = basis.interpolate(edge_basis, u.clone().requires_grad_(True))
+        reference_path = tf().Basis(mesh, tf().ElementTri(1, 3))
+        reference_path.edge_kernel = False  # the reference's expression sequence, run by torch
+        want_val, want_grad = reference_path.interpolate(edge_basis, u)
         assert want_val.shape == val.shape and want_grad.shape == grad.shape
-        assert scaled_error(val.cpu(), want_val.detach().cpu()) <= tol
-        assert scaled_error(grad.cpu(), want_grad.detach().cpu()) <= tol
+        assert scaled_error(val.cpu(), want_val.cpu()) <= tol
+        assert scaled_error(grad.cpu(), want_grad.cpu()) <= tol
+        # derivative in the nodal values: tfem_edge_interpolate_p1_backward against autograd
+        # through the expressions (a jump-like loss: weighted values + squared gradients)
+        weights = torch.linspace(0.5, 1.5, val.numel()).reshape(val.shape).to(dtype)
+        grads = []
+        for b in (basis, reference_path):
+            u_var = u.clone().requires_grad_(True)
+            v_, g_ = b.interpolate(edge_basis, u_var)
+            ((weights * v_).sum() + (g_ ** 2).sum()).backward()
+            grads.append(u_var.grad.detach().cpu())
+        assert grads[0].shape == u.shape
+        assert scaled_error(grads[0], grads[1]) <= (1e-12 if dtype == torch.float64 else 1e-4)
         if dtype == torch.float64:  # and against the numpy oracle (pinned by the reference's fixture)
             o_val, o_grad = orc.edge_interpolate_p1(
                 mesh_np["vertices"], mesh_np["triangles"], mesh["interior_edges", "cells"].cpu().numpy(),

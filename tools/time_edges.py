@@ -41,8 +41,9 @@ def timed(fn, reps):
 
 
 us_k, (val, grad) = timed(lambda: basis.interpolate(edge_basis, u), 50)
-u_grad = u.clone().requires_grad_(True)
-us_t, (val_t, grad_t) = timed(lambda: basis.interpolate(edge_basis, u_grad), 5)
+expressions = tf.Basis(mesh, tf.ElementTri(1, 3))
+expressions.edge_kernel = False  # the reference's expression sequence, run by torch
+us_t, (val_t, grad_t) = timed(lambda: expressions.interpolate(edge_basis, u), 5)
 scale = float(grad_t.detach().abs().max())
 # compulsory traffic per edge: 2 cell ids (16 B), 2 x 3 vertex ids (24 B), Q points (16 Q B),
 # outputs 2 Q values + 4 gradient entries; vertex data comes from cache (each vertex ~6 edges)
@@ -52,3 +53,17 @@ print(f"kernel (tfem_edge_interpolate_p1): {us_k:.1f} us = {algo / us_k / 1e3:.0
       f"{float((val - val_t.detach()).abs().max()):.2e}, gradient {float((grad - grad_t.detach()).abs().max()) / scale:.2e} (scaled)")
 jump = (grad[:, 0] - grad[:, 1])
 print(f"gradient jump over the edges: max {float(jump.abs().max()):.3e}")
+
+
+def loss_step(b):
+    u_var = u.clone().requires_grad_(True)
+    v_, g_ = b.interpolate(edge_basis, u_var)
+    ((g_[:, 0] - g_[:, 1]) ** 2).sum().backward()
+    return u_var.grad
+
+
+us_kb, gk = timed(lambda: loss_step(basis), 20)
+us_tb, gt = timed(lambda: loss_step(expressions), 5)
+print(f"forward + backward of a squared-jump loss: kernels {us_kb:.0f} us, torch expressions {us_tb:.0f} us "
+      f"({us_tb / us_kb:.0f}x); max scaled difference of the nodal gradient "
+      f"{float((gk - gt).abs().max() / gt.abs().max()):.2e}")
