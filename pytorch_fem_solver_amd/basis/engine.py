@@ -280,17 +280,26 @@ class AssemblyEngine:
     def _stream(self):
         return _native.current_stream(self.device)
 
+    def _pairs(self, tensor):
+        """Contiguous and aligned for the kernels' (x, y) pair accesses (a contiguous view can
+        start anywhere inside its storage)."""
+        tensor = tensor.contiguous()
+        return tensor if tensor.data_ptr() % (2 * self.real_bytes) == 0 else tensor.clone()
+
     def _edge_inputs(self, edge_cells, points):
         if self.poly_order != 1 or self.n_fractures:
             raise NotImplementedError("edge interpolation kernel: P1 on one 2-D mesh")
         dev = self.device
         cells = edge_cells.to(dev, torch.int64).contiguous()
-        points = points.detach().to(dev, self.dtype).contiguous()
+        points = self._pairs(points.detach().to(dev, self.dtype))
         n_edges, n_points = int(points.shape[0]), int(points.shape[1])
         if tuple(cells.shape) != (n_edges, 2) or points.dim() != 3 or points.shape[2] != 2:
             raise ValueError("edge interpolation: edge_cells (N_e, 2) and points (N_e, Q, 2) expected")
-        if n_edges and (int(cells.min()) < 0 or int(cells.max()) >= self.n_elems):
-            raise IndexError("edge interpolation: cell id outside the mesh")
+        key = (cells.data_ptr(), n_edges)  # ids are checked once per table (two device syncs)
+        if n_edges and key != getattr(self, "_edge_cells_checked", None):
+            if int(cells.min()) < 0 or int(cells.max()) >= self.n_elems:
+                raise IndexError("edge interpolation: cell id outside the mesh")
+            self._edge_cells_checked = key
         return cells, points, n_edges, n_points
 
     def edge_interpolate(self, edge_cells, points, u):
@@ -322,7 +331,7 @@ class AssemblyEngine:
         cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
         dev = self.device
         g_value = g_value.detach().to(dev, self.dtype).reshape(n_edges, 2, n_points).contiguous()
-        g_grad = g_grad.detach().to(dev, self.dtype).reshape(n_edges, 2, 2).contiguous()
+        g_grad = self._pairs(g_grad.detach().to(dev, self.dtype).reshape(n_edges, 2, 2))
         grad_u = torch.empty(self.coords_per_mesh, dtype=self.dtype, device=dev)
         with torch.cuda.device(dev):
             _native.check(

@@ -624,6 +624,17 @@ __global__ __launch_bounds__(kBlock) void k_csr_spmv(const int64_t *rowptr, cons
   if (row < n_rows && sub == 0) y[row] = acc;
 }
 
+// (x, y) pairs as one 16-byte (fp64) / 8-byte (fp32) access: vertex coordinates, edge points,
+// gradients.  The arrays start at allocation boundaries and hold pairs only.
+template <typename T>
+struct alignas(2 * sizeof(T)) Pair {
+  T x, y;
+};
+template <typename T>
+__device__ __forceinline__ Pair<T> load_pair(const T *base, int64_t index) {
+  return *reinterpret_cast<const Pair<T> *>(base + 2 * index);
+}
+
 // P1 field on the two sides of every interior edge (Basis.interpolate(InteriorEdgesBasis, u),
 // reference basis.py:98-177 with the tensor argument): one lane per (edge, side).  The lane
 // rebuilds the side's affine map from the three vertices (element_tri.py:132-145), pulls the
@@ -638,18 +649,20 @@ __global__ __launch_bounds__(kBlock) void k_edge_interpolate_p1(
   if (side >= n_sides) return;
   const int64_t cell = edge_cells[side];
   const int32_t v0 = conn[3 * cell], v1 = conn[3 * cell + 1], v2 = conn[3 * cell + 2];
-  const T x0 = coords[2 * int64_t(v0)], y0 = coords[2 * int64_t(v0) + 1];
-  const T a = coords[2 * int64_t(v1)] - x0, c = coords[2 * int64_t(v1) + 1] - y0;
-  const T b = coords[2 * int64_t(v2)] - x0, d = coords[2 * int64_t(v2) + 1] - y0;
+  const Pair<T> p0 = load_pair(coords, v0), p1 = load_pair(coords, v1), p2 = load_pair(coords, v2);
+  const T x0 = p0.x, y0 = p0.y;
+  const T a = p1.x - x0, c = p1.y - y0;
+  const T b = p2.x - x0, d = p2.y - y0;
   const T inv_det = T(1) / (a * d - b * c);
   const T i00 = inv_det * d, i01 = inv_det * (-b), i10 = inv_det * (-c), i11 = inv_det * a;
   const T u0 = u[v0], u1 = u[v1], u2 = u[v2];
   // rows of barycentric_grad @ J^-1: (-i0 - i1, i0, i1)
-  grad[2 * side] = u0 * (-i00 - i10) + u1 * i00 + u2 * i10;
-  grad[2 * side + 1] = u0 * (-i01 - i11) + u1 * i01 + u2 * i11;
+  *reinterpret_cast<Pair<T> *>(grad + 2 * side) =
+      Pair<T>{u0 * (-i00 - i10) + u1 * i00 + u2 * i10, u0 * (-i01 - i11) + u1 * i01 + u2 * i11};
   const T *pts = points + (side >> 1) * int64_t(2 * n_points);
   for (int q = 0; q < n_points; ++q) {
-    const T dx = pts[2 * q] - x0, dy = pts[2 * q + 1] - y0;
+    const Pair<T> pq = load_pair(pts, q);
+    const T dx = pq.x - x0, dy = pq.y - y0;
     const T xi = dx * i00 + dy * i01, eta = dx * i10 + dy * i11;
     value[side * n_points + q] = u0 * (T(1) - xi - eta) + u1 * xi + u2 * eta;
   }
@@ -667,18 +680,21 @@ __global__ __launch_bounds__(kBlock) void k_edge_interpolate_p1_backward(
   if (side >= n_sides) return;
   const int64_t cell = edge_cells[side];
   const int32_t v0 = conn[3 * cell], v1 = conn[3 * cell + 1], v2 = conn[3 * cell + 2];
-  const T x0 = coords[2 * int64_t(v0)], y0 = coords[2 * int64_t(v0) + 1];
-  const T a = coords[2 * int64_t(v1)] - x0, c = coords[2 * int64_t(v1) + 1] - y0;
-  const T b = coords[2 * int64_t(v2)] - x0, d = coords[2 * int64_t(v2) + 1] - y0;
+  const Pair<T> p0 = load_pair(coords, v0), p1 = load_pair(coords, v1), p2 = load_pair(coords, v2);
+  const T x0 = p0.x, y0 = p0.y;
+  const T a = p1.x - x0, c = p1.y - y0;
+  const T b = p2.x - x0, d = p2.y - y0;
   const T inv_det = T(1) / (a * d - b * c);
   const T i00 = inv_det * d, i01 = inv_det * (-b), i10 = inv_det * (-c), i11 = inv_det * a;
-  const T gx = g_grad[2 * side], gy = g_grad[2 * side + 1];
+  const Pair<T> gg = load_pair(g_grad, side);
+  const T gx = gg.x, gy = gg.y;
   T w0 = gx * (-i00 - i10) + gy * (-i01 - i11);
   T w1 = gx * i00 + gy * i01;
   T w2 = gx * i10 + gy * i11;
   const T *pts = points + (side >> 1) * int64_t(2 * n_points);
   for (int q = 0; q < n_points; ++q) {
-    const T dx = pts[2 * q] - x0, dy = pts[2 * q + 1] - y0;
+    const Pair<T> pq = load_pair(pts, q);
+    const T dx = pq.x - x0, dy = pq.y - y0;
     const T xi = dx * i00 + dy * i01, eta = dx * i10 + dy * i11;
     const T gv = g_value[side * n_points + q];
     w0 = w0 + gv * (T(1) - xi - eta);
