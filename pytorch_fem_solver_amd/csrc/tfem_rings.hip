@@ -320,14 +320,15 @@ __device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, Ring
 // the ids of the owned vertices nor the row offsets are read from memory.  Scalar loads with a
 // wave-uniform index (the plan is immutable during the launch: constant address space).
 struct RingDesc {
-  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0, elem_off, n_elem;
+  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0, elem_off, n_elem, elem_mode;
 };
+constexpr int kRingElemRuns = 8;  // desc[18] = 1: the tile's elements are <= 8 runs of consecutive ids
 
 template <bool CHUNK>
 __device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigned off_desc, int tile,
                                               int wave) {
   ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 80u * unsigned(tile));
-  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17]};
+  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17], d[18]};
   if (CHUNK) {
     r.gid0 = d[8 + wave];
     r.rs0 = d[12 + wave];
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   };
   auto load_eids = [&](const RingDesc &d, unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
     if (!LOAD || (DBG && (a.flags & 64))) return;  // ablation: no element-id loads
+    if (d.elem_mode) return;                        // runs of consecutive ids: nothing to fetch
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
       const int l = tid + j * kRingBlock;
@@ -474,6 +476,27 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   // past the tile's last element carry the id 0 of the zero-filled load: harmless)
   auto load_fq = [&](const RingDesc &d, const unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
     if (!LOAD || (DBG && (a.flags & 32))) return;  // ablation: no source-value loads
+    if (d.elem_mode) {
+      // position l in the tile's ascending element list -> id, from the first ids of the runs
+      // and the list positions they end at (16 scalars of the plan)
+      ring_const_i32 rg = (ring_const_i32)(uintptr_t)(a.plan + a.off_telems + 4u * unsigned(d.elem_off));
+      int first[kRingElemRuns], upto[kRingElemRuns];
+#pragma unroll
+      for (int r = 0; r < kRingElemRuns; ++r) {
+        first[r] = rg[r];
+        upto[r] = rg[kRingElemRuns + r];
+      }
+#pragma unroll
+      for (int j = 0; j < kRingElemPerLane; ++j) {
+        const int l = tid + j * kRingBlock;
+        int id = first[0] + l;
+#pragma unroll
+        for (int r = 1; r < kRingElemRuns; ++r) id = l >= upto[r - 1] ? first[r] + (l - upto[r - 1]) : id;
+        ring_load_fq<T, QL>(r_fq, l < d.n_elem ? unsigned(id) * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u,
+                            fqe_ld[LOAD ? j : 0]);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
       const int l = tid + j * kRingBlock;

@@ -39,6 +39,7 @@ namespace tfem {
 constexpr int kRingDescStride = 20;
 constexpr int kRingLayoutLen = 24;
 constexpr int kRingElemCap = 768;  // elements staged per tile: three per lane of the kernel
+constexpr int kRingElemRuns = 8;   // runs of consecutive element ids a tile may store instead of its list
 constexpr int kRingHaloCapHost = 256;  // halo vertices per tile: one per lane of the kernel
 
 struct RingPlan {
@@ -195,6 +196,9 @@ template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
                 bool chunk_mode, RingPlan &plan) {
+  // TFEM_RING_ELEM_RANGES=0: every tile stores its element list (A/B of the range encoding)
+  const char *ranges_env = std::getenv("TFEM_RING_ELEM_RANGES");
+  const bool elem_ranges = !(ranges_env && ranges_env[0] == '0');
   int64_t longest = 0;
   for (int64_t v = 0; v < n_verts; ++v) longest = std::max(longest, rowptr[v + 1] - rowptr[v]);
   if (longest > 16)
@@ -331,7 +335,32 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     const int32_t n_elem = int32_t(elems_here.size());
     if (n_elem > kRingElemCap) plan.elems_staged = false;
     for (int32_t j = 0; j < n_elem; ++j) elem_local[size_t(elems_here[size_t(j)])] = j;
-    plan.tile_elems.insert(plan.tile_elems.end(), elems_here.begin(), elems_here.end());
+    // Element numberings with locality: the ascending list is a few runs of consecutive ids.
+    // Up to kRingElemRuns of them are stored as 16 ints -- first id of every run, then the
+    // number of elements up to and including every run (n_elem for the unused ones) -- and the
+    // kernel derives the ids (desc[18] = 1); otherwise the list itself (desc[18] = 0).
+    int32_t elem_mode = 0;
+    if (elem_ranges && n_elem > 2 * kRingElemRuns) {
+      int32_t start[kRingElemRuns], upto[kRingElemRuns];
+      int runs = 0;
+      for (int32_t j = 0; j < n_elem; ++j) {
+        if (j == 0 || elems_here[size_t(j)] != elems_here[size_t(j) - 1] + 1) {
+          if (++runs > kRingElemRuns) break;
+          start[runs - 1] = elems_here[size_t(j)];
+        }
+        upto[runs - 1] = j + 1;
+      }
+      if (runs <= kRingElemRuns) {
+        for (int r = runs; r < kRingElemRuns; ++r) {
+          start[r] = 0;
+          upto[r] = n_elem;
+        }
+        plan.tile_elems.insert(plan.tile_elems.end(), start, start + kRingElemRuns);
+        plan.tile_elems.insert(plan.tile_elems.end(), upto, upto + kRingElemRuns);
+        elem_mode = 1;
+      }
+    }
+    if (!elem_mode) plan.tile_elems.insert(plan.tile_elems.end(), elems_here.begin(), elems_here.end());
     plan.max_n_elem = std::max(plan.max_n_elem, n_elem);
     const int ewords = (plan.slots + 1) / 2;
     for (int l = 0; l < n_own; ++l) {
@@ -348,7 +377,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     }
     int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
                                   wave_start[1], wave_start[2], wave_start[3], n_own,
-                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, 0, 0};
+                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, elem_mode, 0};
     plan.max_n_halo = std::max(plan.max_n_halo, next_local - n_own);
     for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
       if (wave_start[w] < wave_start[w + 1]) {

@@ -57,7 +57,15 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         xy = coords[gid]
         rec = decode_rows(rows[row_off:row_off + n_own], slots)
         elem_off, n_elem = int(d[16]), int(d[17])
-        tile_elems = plan["tile_elems"][elem_off:elem_off + n_elem]
+        if int(d[18]):  # <= 8 runs of consecutive ids: first ids, then list positions they end at
+            first, upto = plan["tile_elems"][elem_off:elem_off + 8], plan["tile_elems"][elem_off + 8:elem_off + 16]
+            pos = np.arange(n_elem)
+            tile_elems = first[0] + pos
+            for r in range(1, 8):
+                tile_elems = np.where(pos >= upto[r - 1], first[r] + (pos - upto[r - 1]), tile_elems)
+            assert upto[7] == n_elem
+        else:
+            tile_elems = plan["tile_elems"][elem_off:elem_off + n_elem]
         assert np.all(np.diff(tile_elems) > 0) and (n_elem <= 768 or not plan["elems_staged"])
         rowstart = plan["rowstart"][row_off:row_off + n_own]
         for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
