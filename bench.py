@@ -77,6 +77,28 @@ def measured_traffic(n, order, kernel, with_load):
     return None
 
 
+def profiled_kernel_ms(kernel, with_load):
+    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary
+    of this command (profiles/r01_bench_kernel_stats.csv), or None.  The HIP-event interval
+    around ONE launch (roofline.kernel_ms) also holds the launch and completion latency of the
+    dispatch (~10-15 us for this grid); the profiler's figure is the kernel alone."""
+    import csv
+
+    path = os.path.join(REPO, "profiles", "r01_bench_kernel_stats.csv")
+    try:
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row["Name"]
+                if kernel + "<double" not in name:
+                    continue
+                q = int(name.split("<", 1)[1].split(",")[4])
+                if (q > 0) == with_load:
+                    return float(row["AverageNs"]) * 1e-6
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
+    return None
+
+
 def cpu_baseline(n, order):
     """The C/OpenMP oracle (oracle/assembly_oracle.c: a port of the reference's op sequence,
     one element per iteration) timed on this host's cores: local K + local f + scatter into
@@ -314,6 +336,9 @@ def main():
             },
         }
         # what the HBM interface moved (PMC bytes of profiles/) over the live launch duration
+        if n == 2236 and args.order == 3:  # the profiled workload
+            line["roofline"]["kernel_ms_rocprofv3"] = profiled_kernel_ms(engine.kernel_name(), True)
+            line["roofline"]["stiffness_only"]["kernel_ms_rocprofv3"] = profiled_kernel_ms(engine.kernel_name(), False)
         for obj, ms in ((line["roofline"], k_ms), (line["roofline"]["stiffness_only"], k_only_ms)):
             if obj["traffic"]:
                 obj["traffic_GBps"] = obj["traffic"] / (ms * 1e-3) / 1e9
