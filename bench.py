@@ -259,17 +259,17 @@ def main():
 
     # an idle device runs its first ~20 ms of this launch slower (profiles/r01_launch_series.log:
     # 221 us per launch over the first 50, 186 over the next 50, 179 from then on), so the device
-    # is brought to its steady state with 30 ms of the same steps before the W warm-up steps the
-    # caller asked for; reported in config.device_warmup_ms
-    device_warmup_ms = 30.0
-    t_warm = time.perf_counter()
-    while (time.perf_counter() - t_warm) * 1e3 < device_warmup_ms:
-        for _ in range(10):
-            claim_pair()
-            out = step()
-            if exchange is not None:
-                exchange_step(*out)
-        torch.cuda.synchronize()
+    # is brought to its steady state with 170 of the same steps (30 ms) before the W warm-up steps
+    # the caller asked for; reported in config.device_warmup_steps
+    # (a fixed count, the same on every rank: the steps of an N > 1 run hold collectives)
+    device_warmup_steps = 170
+    for k in range(device_warmup_steps):
+        claim_pair()
+        out = step()
+        if exchange is not None:
+            exchange_step(*out)
+        if k % 10 == 9:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         claim_pair()
@@ -334,7 +334,7 @@ def main():
                 "elements_per_gpu": n_elems,
                 "partition": "one unit-square strip per rank" if world > 1 else "single mesh",
                 "kernel": engine.kernel_name(),
-                "device_warmup_ms": device_warmup_ms,
+                "device_warmup_steps": device_warmup_steps,
                 "probe_every": probe,
             },
             "roofline": {
