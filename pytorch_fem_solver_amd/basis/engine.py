@@ -176,7 +176,7 @@ def unpack_ring_plan(blob, layout):
         "rows": view(1, np.uint32, z[7] * z[1]),
         "rowstart": view(2, np.int32, z[1]),
         "vert_gid": view(3, np.int32, z[2]),
-        "row_ecodes": np.frombuffer(blob, dtype=np.uint32, count=((z[6] + 1) // 2) * z[1], offset=z[15]),
+        "row_ecodes": np.frombuffer(blob, dtype=np.uint32, count=((12 * z[6] + 31) // 32) * z[1], offset=z[15]),
         "tile_elems": np.frombuffer(blob, dtype=np.int32, count=z[19], offset=z[16]),
         "elems_staged": bool(z[18]),
     }

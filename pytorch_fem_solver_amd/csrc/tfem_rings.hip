@@ -398,7 +398,7 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 // (plan: tile_elems, ascending) are fetched ONCE per tile with coalesced 16-byte loads -- three
 // elements per lane, prefetched like the coordinates -- reduced to the three numbers g[T][.]
 // and staged in LDS; a row reads one of them per fan slot by the slot's
-// 16-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
+// 12-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
 // instead is bound by the texture addresser: 14 scattered loads per row.)
 template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
 // The matrix-only 15-slot instantiations are asked for 3 waves per SIMD: left alone, hipcc's
@@ -407,7 +407,7 @@ template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool K
 __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_p1_rings(const RingArgs<T> a) {
   constexpr bool LOAD = QL > 0;
   static_assert(KMAT || LOAD, "nothing to assemble");
-  constexpr int kEW = (SLOTS + 1) / 2;  // dwords of slot codes per row
+  constexpr int kEW = (12 * SLOTS + 31) / 32;  // dwords of packed 12-bit slot codes per row: 3 or 6
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
   T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
   T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
@@ -528,15 +528,14 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
       if (!CHUNK)
         rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
-      if (LOAD) {  // 16-bit slot codes: 4 (SLOTS 7) or 8 dwords per row
+      if (LOAD) {  // 12-bit slot codes: 3 (SLOTS 7) or 6 dwords per row
         const unsigned eb = a.off_elems + row * unsigned(4 * kEW);
 #pragma unroll
-        for (int i = 0; i < kEW; i += 4) {
-          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, eb + unsigned(4 * i), 0, kStreamLoadNT);
+        for (int i = 0; i < kEW; i += 3) {
+          const ru32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r_plan, eb + unsigned(4 * i), 0, kStreamLoadNT);
           se_ld[LOAD ? i : 0] = v.x;
           se_ld[LOAD ? i + 1 : 0] = v.y;
           se_ld[LOAD ? i + 2 : 0] = v.z;
-          se_ld[LOAD ? i + 3 : 0] = v.w;
         }
       }
     }
@@ -634,10 +633,12 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       const T *g = gtab;
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
-        // code: tile-local element | loc << 10; 0xFFFF (no triangle) reads the spare entries
+        // code: tile-local element | loc << 10; 0xFFF (no triangle) reads the spare entries
         // behind the table, its determinant is 0
-        const uint32_t code = (se[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
-        const uint32_t at = code == 0xFFFFu ? unsigned(3 * a.lds_elem) : 3u * (code & 0x3FFu) + (code >> 10);
+        const int bit = 12 * i, w0 = bit / 32, sh = bit % 32;  // constants once the loop is unrolled
+        const uint32_t lo = se[w0] >> sh;
+        const uint32_t code = (sh > 20 ? lo | (se[w0 + 1 < kEW ? w0 + 1 : w0] << (32 - sh)) : lo) & 0xFFFu;
+        const uint32_t at = code == 0xFFFu ? unsigned(3 * a.lds_elem) : 3u * (code & 0x3FFu) + (code >> 10);
         facc = facc + sdets[i] * g[at];
       }
     }

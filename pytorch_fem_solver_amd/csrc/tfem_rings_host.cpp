@@ -53,8 +53,8 @@ struct RingPlan {
   std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
   // load vector only.  tile_elems: the elements of every tile's fans (ascending per tile: their
   // source values are fetched once per tile, coalesced, and staged in LDS); row_ecodes: per
-  // owned row one 16-bit code per slot, two per dword: tile-local element index | local index
-  // of the row's vertex in that element << 10 (0xFFFF: no triangle).
+  // owned row one 12-bit code per slot, packed: tile-local element index | local index
+  // of the row's vertex in that element << 10 (0xFFF: no triangle); 12 bits per slot, packed.
   std::vector<int32_t> tile_elems;
   std::vector<uint32_t> row_ecodes;
   int32_t max_n_elem = 0;
@@ -362,16 +362,18 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     }
     if (!elem_mode) plan.tile_elems.insert(plan.tile_elems.end(), elems_here.begin(), elems_here.end());
     plan.max_n_elem = std::max(plan.max_n_elem, n_elem);
-    const int ewords = (plan.slots + 1) / 2;
+    const int ewords = (12 * plan.slots + 31) / 32;  // 12-bit codes, packed: 3 (7 slots) or 6 dwords
     for (int l = 0; l < n_own; ++l) {
       uint32_t ew[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < 2 * ewords; ++i) {
-        uint32_t code = 0xFFFFu;
-        if (i < plan.slots && fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] >= 0) {
+      for (int i = 0; i < plan.slots; ++i) {
+        uint32_t code = 0xFFFu;
+        if (fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] >= 0) {
           const int32_t le = elem_local[size_t(fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)])];
-          code = le < 1023 ? uint32_t(le) | uint32_t(fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)]) << 10 : 0xFFFFu;
+          code = le < 1023 ? uint32_t(le) | uint32_t(fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)]) << 10 : 0xFFFu;
         }
-        ew[i / 2] |= code << (16 * (i % 2));
+        const int bit = 12 * i;
+        ew[bit / 32] |= code << (bit % 32);
+        if (bit % 32 > 20) ew[bit / 32 + 1] |= code >> (32 - bit % 32);
       }
       plan.row_ecodes.insert(plan.row_ecodes.end(), ew, ew + ewords);
     }

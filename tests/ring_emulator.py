@@ -40,7 +40,7 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
     fvec = np.full(coords.shape[0], np.nan) if fq is not None else None
-    ewords = (slots + 1) // 2
+    ewords = (12 * slots + 31) // 32  # packed 12-bit slot codes
     row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
     for d in desc:
         vert_off, n_vert, row_off, ws0, ws1, ws2, ws3, n_own = (int(x) for x in d[:8])
@@ -85,12 +85,13 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
             diag = 0.0
             facc = 0.0
             ew = row_ecodes[row_off + r]
-            se = np.array([(int(ew[i // 2]) >> (16 * (i % 2))) & 0xFFFF for i in range(2 * ewords)])
-            assert np.all(se[k:] == 0xFFFF)
+            bits = sum(int(ew[j]) << (32 * j) for j in range(ewords))
+            se = np.array([(bits >> (12 * i)) & 0xFFF for i in range(slots)])
+            assert np.all(se[k:] == 0xFFF)
             for i in range(k):
                 nxt = 0 if i + 1 == k else i + 1
                 if flag[i] == 0:
-                    assert se[i] == 0xFFFF
+                    assert se[i] == 0xFFF
                     continue
                 dvec = e[nxt] - e[i]
                 cross = e[i, 0] * e[nxt, 1] - e[i, 1] * e[nxt, 0]
