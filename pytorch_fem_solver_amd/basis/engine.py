@@ -251,6 +251,7 @@ class AssemblyEngine:
         self._gather = None
         self._slots_host = None
         self._p2rows = None
+        self._edge_cells_checked = None  # (data_ptr, rows) of the last validated edge -> cells table
         #: "auto" (the best plan the mesh allows), "rings", "tiles", "rows" (P2 row kernels),
         #: "gather" (element blocks / vectors + gather, no plan) or "atomic" (one-pass scatter)
         self.kernel = os.environ.get("TFEM_KERNEL", "auto")
@@ -296,7 +297,7 @@ class AssemblyEngine:
         if tuple(cells.shape) != (n_edges, 2) or points.dim() != 3 or points.shape[2] != 2:
             raise ValueError("edge interpolation: edge_cells (N_e, 2) and points (N_e, Q, 2) expected")
         key = (cells.data_ptr(), n_edges)  # ids are checked once per table (two device syncs)
-        if n_edges and key != getattr(self, "_edge_cells_checked", None):
+        if n_edges and key != self._edge_cells_checked:
             if int(cells.min()) < 0 or int(cells.max()) >= self.n_elems:
                 raise IndexError("edge interpolation: cell id outside the mesh")
             self._edge_cells_checked = key
