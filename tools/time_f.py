@@ -9,8 +9,8 @@ eng = basis._engine
 pts = eng.geometry()[2]
 fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
 del pts
-def t(fn, reps=20):
-    for _ in range(3): fn()
+def t(fn, reps=100):
+    for _ in range(150): fn()  # steady state: the first ~20 ms after an idle phase run slower
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
