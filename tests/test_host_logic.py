@@ -486,3 +486,19 @@ def test_torch_fem_alias_package():
     from torch_fem.mesh import MeshTri as M2
 
     assert B2 is tf.Basis and E2 is tf.ElementTri and M2 is tf.MeshTri
+
+
+def test_bench_reads_the_committed_profiles():
+    """bench.py fills roofline.traffic / kernel_ms_rocprofv3 from the committed rocprofv3
+    summaries under profiles/: both launches of the bench kernel must be found there."""
+    import bench
+
+    for with_load in (True, False):
+        traffic = bench.measured_traffic(2236, 3, "k_p1_rings", with_load)
+        duration = bench.profiled_kernel_ms("k_p1_rings", with_load)
+        assert traffic is not None and duration is not None
+        # compulsory traffic of the launch is below what the counters saw, within 2.5x
+        algo = bench.algorithmic_bytes(9999392, 5004169, 35011289, with_load)
+        assert algo <= traffic <= 2.5 * algo
+        assert 0.05 <= duration <= 0.25  # ms
+    assert bench.measured_traffic(100, 3, "k_p1_rings", True) is None  # another workload: no figure
