@@ -303,12 +303,15 @@ class AssemblyEngine:
             self._edge_cells_checked = key
         return cells, points, n_edges, n_points
 
-    def edge_interpolate(self, edge_cells, points, u):
+    def edge_interpolate(self, edge_cells, points, u, prepared=False):
         """P1 DoF vector u on both sides of the interior edges: one tfem_edge_interpolate_p1
         launch.  edge_cells (N_e, 2) cell ids, points (N_e, Q, 2); returns value (N_e, 2, Q)
         and gradient (N_e, 2, 2) on the compute device."""
         d = self._inputs()
-        cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
+        if prepared:  # the outputs of _edge_inputs, kept by the caller
+            cells, n_edges, n_points = edge_cells, int(points.shape[0]), int(points.shape[1])
+        else:
+            cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
         dev = self.device
         u = u.detach().to(dev, self.dtype).reshape(-1).contiguous()
         if u.numel() != self.coords_per_mesh:
@@ -325,11 +328,14 @@ class AssemblyEngine:
             )
         return value, grad
 
-    def edge_interpolate_backward(self, edge_cells, points, g_value, g_grad):
+    def edge_interpolate_backward(self, edge_cells, points, g_value, g_grad, prepared=False):
         """Adjoint of edge_interpolate in u: (N_v,) on the compute device from the cotangents
         g_value (N_e, 2, Q) and g_grad (N_e, 2, 2); one tfem_edge_interpolate_p1_backward launch."""
         d = self._inputs()
-        cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
+        if prepared:
+            cells, n_edges, n_points = edge_cells, int(points.shape[0]), int(points.shape[1])
+        else:
+            cells, points, n_edges, n_points = self._edge_inputs(edge_cells, points)
         dev = self.device
         g_value = g_value.detach().to(dev, self.dtype).reshape(n_edges, 2, n_points).contiguous()
         g_grad = self._pairs(g_grad.detach().to(dev, self.dtype).reshape(n_edges, 2, 2))

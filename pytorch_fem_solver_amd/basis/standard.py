@@ -23,12 +23,12 @@ class _EdgeInterpolateFunction(torch.autograd.Function):
     def forward(ctx, u, engine, edge_cells, points):
         ctx.engine, ctx.edge_cells, ctx.points = engine, edge_cells, points
         ctx.u_shape, ctx.u_device = u.shape, u.device
-        value, grad = engine.edge_interpolate(edge_cells, points, u)
+        value, grad = engine.edge_interpolate(edge_cells, points, u, prepared=True)
         return value.to(u.device), grad.to(u.device)
 
     @staticmethod
     def backward(ctx, g_value, g_grad):
-        grad_u = ctx.engine.edge_interpolate_backward(ctx.edge_cells, ctx.points, g_value, g_grad)
+        grad_u = ctx.engine.edge_interpolate_backward(ctx.edge_cells, ctx.points, g_value, g_grad, prepared=True)
         return grad_u.reshape(ctx.u_shape).to(ctx.u_device), None, None, None
 
 
@@ -115,11 +115,17 @@ class Basis(AbstractBasis):
             return torch.is_tensor(t) and t.dtype == self._engine.dtype and tuple(t.shape) == (n, 1)
 
         def edge_kernel(values):
+            staged = getattr(basis, "_edge_kernel_inputs", None)
             pts = basis.integration_points
-            n_edges, n_points = pts.shape[0], pts.shape[-2]
-            val, grad = _EdgeInterpolateFunction.apply(
-                values, self._engine, basis.mesh["interior_edges", "cells"],
-                pts.detach().reshape(n_edges, n_points, 2))
+            if staged is None or staged[0] != (id(self._engine), pts.data_ptr()):
+                # device copies of the edge -> cells table and the edge points, validated once
+                n_edges, n_points = pts.shape[0], pts.shape[-2]
+                cells, points, _, _ = self._engine._edge_inputs(
+                    basis.mesh["interior_edges", "cells"], pts.detach().reshape(n_edges, n_points, 2))
+                staged = basis._edge_kernel_inputs = ((id(self._engine), pts.data_ptr()), cells, points)
+            _, cells, points = staged
+            n_edges, n_points = points.shape[0], points.shape[1]
+            val, grad = _EdgeInterpolateFunction.apply(values, self._engine, cells, points)
             return val.reshape(n_edges, 2, n_points, 1, 1), grad.reshape(n_edges, 2, 1, 1, 2)
 
         kernel_ok = self.edge_kernel and on_edges and self._element.polynomial_order == 1
