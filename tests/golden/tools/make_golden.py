@@ -20,13 +20,16 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
 GOLDEN = os.path.abspath(os.path.join(HERE, ".."))
-sys.path.insert(0, os.path.join(HERE, "container_only"))
-sys.path.insert(0, "/root/reference")
+REFERENCE = os.environ.get("TFEM_REFERENCE_ROOT", "/root/reference")
+# the repository also holds a package named torch_fem (the drop-in alias of this build): the
+# reference's must win, so its root goes in front of the repository's
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "container_only"))
+sys.path.insert(0, REFERENCE)
 
 import torch_fem as ref  # noqa: E402  (the reference, /root/reference/torch_fem)
 
-assert ref.__file__.startswith("/root/reference/"), ref.__file__
+assert os.path.abspath(ref.__file__).startswith(os.path.abspath(REFERENCE) + os.sep), ref.__file__
 
 from pytorch_fem_solver_amd import meshgen  # noqa: E402  (inputs only)
 
@@ -270,9 +273,13 @@ def frac_exact_sq(basis):
     return frac_exact(basis.integration_points) ** 2
 
 
-def fracture_case(m, jitter):
+def fracture_case(m, jitter, compact=False):
+    """compact: the inputs are the generator's arguments (the mesh is rebuilt by the test),
+    the dense operator is stored as its nonzero entries and only O(N) outputs are kept."""
     torch.set_default_dtype(torch.float64)
     tri = meshgen.fracture_rectangle(m, jitter=jitter, seed=2)
+    if compact:
+        return fracture_case_compact(m, jitter, tri)
     data = mesh_inputs(tri)
     data["in_fractures_3d"] = np.array(FRACTURES_3D)
     mesh = ref.FracturesTri(
@@ -318,32 +325,90 @@ def fracture_case(m, jitter):
     return data
 
 
-def save(name, data):
-    path = os.path.join(GOLDEN, name)
-    np.savez_compressed(path, **data)
-    print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+def fracture_case_compact(m, jitter, tri):
+    data = {"in_m": np.int64(m), "in_jitter": np.float64(jitter), "in_seed": np.int64(2),
+            "in_vertices_sha": np.frombuffer(_sha(tri["vertices"], tri["triangles"]), dtype=np.uint8),
+            "in_fractures_3d": np.array(FRACTURES_3D)}
+    mesh = ref.FracturesTri(
+        triangulations=[tri, tri], fractures_3d_data=torch.tensor(FRACTURES_3D)
+    )
+    V = ref.FractureBasis(mesh, ref.ElementTri(polynomial_order=1, integration_order=4))
+    A = V.integrate_bilinear_form(stiffness)
+    b = V.integrate_linear_form(frac_load)
+    rows, cols = torch.nonzero(A, as_tuple=True)
+    data["out_A_shape"] = np.array(A.shape, dtype=np.int64)
+    data["out_A_rows"] = npy(rows).astype(np.int32)
+    data["out_A_cols"] = npy(cols).astype(np.int32)
+    data["out_A_vals"] = npy(A[rows, cols])
+    data["out_b"] = npy(b)
+    data["out_inner_dofs"] = npy(V._basis_parameters["inner_dofs"]).astype(np.int32)
+    data["out_gt_triangles"] = npy(V.global_triangulation["triangles"]).astype(np.int32)
+    data["out_functional_exact_sq_sum"] = npy(V.integrate_functional(frac_exact_sq).sum())
+    u_h = V.solve(A, V.solution_tensor(), b)
+    del A
+    data["out_u_h"] = npy(u_h)
+    VE = ref.InteriorEdgesFractureBasis(
+        mesh, ref.ElementLine(polynomial_order=1, integration_order=2)
+    )
+    _, eg = V.interpolate(VE, u_h)
+    n_E = mesh["interior_edges", "normals_3d"].unsqueeze(-2)
+    plus, minus = torch.unbind(eg, dim=-4)  # example_fractures_fem.py:295-297
+    data["out_jump"] = npy((plus * n_E).sum(-1) + (minus * -n_E).sum(-1))
+    return data
+
+
+def _sha(*arrays):
+    import hashlib
+
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
+def clockwise_mixed():
+    cw = meshgen.unit_square(5, 0.2, 1)
+    cw["triangles"][::3] = cw["triangles"][::3][:, [0, 2, 1]]
+    return cw
+
+
+#: fixture -> thunk producing its arrays
+CASES = {
+    # C1: jittered structured square (128 elements), all four quadrature rules
+    "p1_square_n8.npz": lambda: p1_case(meshgen.unit_square(8, 0.25, 0), (1, 2, 3, 4)),
+    # C1: clockwise triangles mixed in -> signed determinants (SURVEY section 0 item 6)
+    "p1_square_n5_clockwise.npz": lambda: p1_case(clockwise_mixed(), (3,)),
+    # C1 stand-in for the "qea0.005" mesh of tests/test_assembly.py (~300 elements)
+    "p1_delaunay_170.npz": lambda: p1_case(meshgen.delaunay_square(170, 1), (3,)),
+    # float32 default dtype (examples/example_weak.py:20)
+    "p1_square_n6_float32.npz": lambda: p1_case(meshgen.unit_square(6, 0.25, 4), (4,), dtype=torch.float32),
+    "mesh_topology_n4.npz": lambda: mesh_topology_case(meshgen.unit_square(4, 0.2, 7)),
+    "p2_element.npz": p2_element_case,
+    "p2_global_n4.npz": lambda: p2_global_case(meshgen.unit_square(4, 0.25, 3)),
+    "fracture_L4.npz": lambda: fracture_case(4, 0.0),
+    "fracture_L3_jitter.npz": lambda: fracture_case(3, 0.2),
+    # SURVEY 8(d) C5 at m = 64 (2 x 16,384 cells): the dense operator (2.2 GB) is kept as its
+    # nonzero entries, the O(N) outputs whole
+    "fracture_L64.npz": lambda: fracture_case(64, 0.0, compact=True),
+}
 
 
 def main():
-    torch.manual_seed(0)
-    # C1: jittered structured square (128 elements), all four quadrature rules
-    save("p1_square_n8.npz", p1_case(meshgen.unit_square(8, 0.25, 0), (1, 2, 3, 4)))
-    # C1: clockwise triangles mixed in -> signed determinants (SURVEY section 0 item 6)
-    cw = meshgen.unit_square(5, 0.2, 1)
-    cw["triangles"][::3] = cw["triangles"][::3][:, [0, 2, 1]]
-    save("p1_square_n5_clockwise.npz", p1_case(cw, (3,)))
-    # C1 stand-in for the "qea0.005" mesh of tests/test_assembly.py (~300 elements)
-    save("p1_delaunay_170.npz", p1_case(meshgen.delaunay_square(170, 1), (3,)))
-    # float32 default dtype (examples/example_weak.py:20)
-    save(
-        "p1_square_n6_float32.npz",
-        p1_case(meshgen.unit_square(6, 0.25, 4), (4,), dtype=torch.float32),
-    )
-    save("mesh_topology_n4.npz", mesh_topology_case(meshgen.unit_square(4, 0.2, 7)))
-    save("p2_element.npz", p2_element_case())
-    save("p2_global_n4.npz", p2_global_case(meshgen.unit_square(4, 0.25, 3)))
-    save("fracture_L4.npz", fracture_case(4, 0.0))
-    save("fracture_L3_jitter.npz", fracture_case(3, 0.2))
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=GOLDEN, help="directory the fixtures are written to")
+    ap.add_argument("--only", nargs="*", default=None, help="fixture names (default: all)")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name, thunk in CASES.items():
+        if args.only is not None and name not in args.only:
+            continue
+        torch.manual_seed(0)
+        data = thunk()
+        path = os.path.join(args.out, name)
+        np.savez_compressed(path, **data)
+        print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.1f} KiB", flush=True)
 
 
 if __name__ == "__main__":

@@ -263,6 +263,65 @@ def test_fracture_example_pipeline(fixture):
     assert scaled_error(jump.cpu(), d["out_jump"]) <= 1e-9
 
 
+def test_fracture_example_pipeline_m64():
+    """Config 5 at SURVEY 8(d)'s larger size (m = 64: 2 x 16,384 cells, 16,705 DoFs): operator
+    (compared on the reference's nonzero entries and by its total), load vector, solution and
+    jump against the reference-generated fixture; the mesh is rebuilt from the generator's
+    arguments and checked against the fixture's digest."""
+    import hashlib
+
+    from pytorch_fem_solver_amd import meshgen
+
+    d = load_golden("fracture_L64.npz")
+    tri = meshgen.fracture_rectangle(int(d["in_m"]), jitter=float(d["in_jitter"]), seed=int(d["in_seed"]))
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(tri["vertices"]).tobytes())
+    h.update(np.ascontiguousarray(tri["triangles"]).tobytes())
+    assert h.digest() == d["in_vertices_sha"].tobytes(), "the generator no longer builds the fixture's mesh"
+    mesh = tf().FracturesTri(triangulations=[tri, tri], fractures_3d_data=torch.tensor(d["in_fractures_3d"]))
+    V = tf().FractureBasis(mesh, tf().ElementTri(polynomial_order=1, integration_order=4))
+
+    def frac_rhs(c):
+        x, y, z = torch.split(c, 1, dim=-1)
+        x1, _ = torch.split(x, 1, dim=0)
+        y1, y2 = torch.split(y, 1, dim=0)
+        _, z2 = torch.split(z, 1, dim=0)
+        r1 = 6.0 * (y1 - y1**2) * torch.abs(x1) - 2.0 * (torch.abs(x1) ** 3 - torch.abs(x1))
+        r2 = -6.0 * (y2 - y2**2) * torch.abs(z2) + 2.0 * (torch.abs(z2) ** 3 - torch.abs(z2))
+        return torch.cat([r1, r2], dim=0)
+
+    def exact(c):
+        x, y, z = torch.split(c, 1, dim=-1)
+        x1, _ = torch.split(x, 1, dim=0)
+        y1, y2 = torch.split(y, 1, dim=0)
+        _, z2 = torch.split(z, 1, dim=0)
+        e1 = -y1 * (1 - y1) * torch.abs(x1) * (x1**2 - 1)
+        e2 = y2 * (1 - y2) * torch.abs(z2) * (z2**2 - 1)
+        return torch.cat([e1, e2], dim=0)
+
+    A = V.integrate_bilinear_form(stiffness)
+    assert tuple(A.shape) == tuple(int(x) for x in d["out_A_shape"])
+    rows, cols = torch.tensor(d["out_A_rows"]).long(), torch.tensor(d["out_A_cols"]).long()
+    want_vals = d["out_A_vals"]
+    assert scaled_error(A[rows, cols].cpu(), want_vals) <= TOL
+    # nothing outside the reference's nonzero entries beyond rounding (cancelled entries)
+    assert abs(float(A.abs().sum()) - np.abs(want_vals).sum()) <= 1e-9 * np.abs(want_vals).sum()
+    b = V.integrate_linear_form(lambda basis: frac_rhs(basis.integration_points) * basis.v)
+    assert scaled_error(b.cpu(), d["out_b"]) <= TOL
+    assert np.array_equal(V._basis_parameters["inner_dofs"].cpu().numpy().astype(np.int32).ravel(),
+                          d["out_inner_dofs"].ravel())
+    fun = V.integrate_functional(lambda basis: exact(basis.integration_points) ** 2)
+    assert abs(float(fun.sum()) - float(d["out_functional_exact_sq_sum"])) <= 1e-12 * abs(float(d["out_functional_exact_sq_sum"]))
+    u_h = V.solve(A, V.solution_tensor(), b)
+    assert scaled_error(u_h.cpu(), d["out_u_h"]) <= 1e-9
+    VE = tf().InteriorEdgesFractureBasis(mesh, tf().ElementLine(polynomial_order=1, integration_order=2))
+    _, eg = V.interpolate(VE, u_h)
+    n_E = mesh["interior_edges", "normals_3d"].unsqueeze(-2)
+    plus, minus = torch.unbind(eg, dim=-4)
+    jump = (plus * n_E).sum(-1) + (minus * -n_E).sum(-1)
+    assert scaled_error(jump.cpu(), d["out_jump"]) <= 1e-8
+
+
 def test_interior_edges_basis_and_interpolation():
     d = load_golden("mesh_topology_n4.npz")
     mesh = tf().MeshTri(triangulation=mesh_from_golden(d))

@@ -136,6 +136,29 @@ def test_fracture_geometry_and_assembly(fixture):
     assert scaled_error(orc.assemble_dense_bilinear(k, conn, n), d["out_A"]) <= TOL
 
 
+def test_fracture_assembly_m64():
+    """The oracle against the reference's operator at SURVEY 8(d)'s C5 size m = 64 (fixture
+    keeps the nonzero entries of the 16,705^2 dense operator and the load vector)."""
+    import scipy.sparse as sp
+
+    from pytorch_fem_solver_amd import meshgen
+
+    d = load_golden("fracture_L64.npz")
+    tri = meshgen.fracture_rectangle(int(d["in_m"]), jitter=float(d["in_jitter"]), seed=int(d["in_seed"]))
+    verts = np.stack([tri["vertices"]] * 2)
+    tris = tri["triangles"].astype(np.int64)
+    fmap = orc.fracture_map(verts, d["in_fractures_3d"])
+    geo = orc.fracture_geometry(verts[:, tris], fmap, 4)
+    conn = d["out_gt_triangles"].reshape(-1, 3).astype(np.int64)
+    n = int(d["out_A_shape"][0])
+    k = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"]).reshape(-1, 3, 3)
+    rows, cols = orc.scatter_indices(conn)
+    A = sp.coo_matrix((k.reshape(-1), (rows, cols)), shape=(n, n)).tocsr()
+    got = np.asarray(A[d["out_A_rows"], d["out_A_cols"]]).ravel()
+    assert scaled_error(got, d["out_A_vals"]) <= TOL
+    assert abs(np.abs(A.data).sum() - np.abs(d["out_A_vals"]).sum()) <= 1e-9 * np.abs(d["out_A_vals"]).sum()
+
+
 def test_edge_interpolation_restatement():
     """oracle.edge_interpolate_p1 against the reference's Basis.interpolate(InteriorEdgesBasis, u)
     output (make_golden.py), with the reference's own edge -> cells table and edge points."""
