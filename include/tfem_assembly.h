@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TFEM_ABI_VERSION 1
+#define TFEM_ABI_VERSION 2
 
 typedef enum tfem_status {
   TFEM_OK = 0,
@@ -268,7 +268,11 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *            vertices (tiles made of chunks of the numbering) [14] max halo vertices/tile
  *            [15] byte offset of row_ecodes, [16] of tile_elems in the packed plan [17] max
  *            elements per tile [18] 1 when every tile's elements fit the kernel's LDS stage
- *            (the fused load vector needs it) [19] entries of tile_elems [20..23] reserved
+ *            (the fused load vector needs it) [19] entries of tile_elems [20] byte offset of
+ *            tile_tverts (uint32 per tile element, in the order of the tile's ascending element
+ *            list: the three tile-local vertex ids of the element in its own local order,
+ *            10 bits each; desc[19] of a tile = its offset into this array), 0 when absent
+ *            [21] entries of tile_tverts [22..23] reserved
  *   pack   : desc int32 (20 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
  *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
  *            wave 0..3, CSR offset of the first row of wave 0..3, offset into tile_elems,
@@ -295,6 +299,69 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
                            double alpha, double beta, const void *plan_device,
                            const int64_t *plan_layout_host, void *vals, int64_t nnz,
                            const void *fq, int64_t n_elems, void *fout, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Source programs: the coefficient f of the linear form f(x_q) * v
+ * (abstract_basis.py:95-112 with the callers' closed vocabulary, SURVEY 8 a-7:
+ * tests/test_assembly.py:75-84, examples/example_weak.py:59-61 ...) as a postfix
+ * program over the coordinates (x, y) of an integration point, evaluated inside the
+ * kernels at x_q = bar(q)^T X (basis.py:90-91).  The reference evaluates the user's
+ * torch expressions on the cached (n_elems, Q, 1, 2) tensor and multiplies by v on
+ * every call; here the Python tracer (pytorch_fem_solver_amd/basis/forms.py) records
+ * those expressions once and the assembly launch re-evaluates them, so the 8 Q bytes
+ * per element of pre-evaluated source values never exist in HBM.
+ *   A stack machine of TFEM_SOURCE_STACK entries.  ops[i] with constant consts[i]:
+ *   PUSH_X / PUSH_Y / PUSH_C   push x, y, or the constant
+ *   ADD SUB MUL DIV            pop hi, pop lo, push lo (op) hi;  SUB_R, DIV_R: hi (op) lo
+ *   ADD_C MUL_C RSUB_C RDIV_C  top = top + c, top * c, c - top, c / top
+ *   NEG ABS SIN COS EXP SQRT LOG TANH   top = fn(top)
+ *   POW_I                      top = top^n, n = (int)c in 2..8, by multiplications
+ *                              from the left (x*x, x*x*x as torch evaluates them)
+ * A valid program never pops an empty stack, never exceeds the stack and leaves
+ * exactly one entry: the value of f.
+ * ------------------------------------------------------------------------- */
+#define TFEM_SOURCE_MAX_OPS 32
+#define TFEM_SOURCE_STACK 4
+enum tfem_source_op {
+  TFEM_SRC_END = 0,
+  TFEM_SRC_PUSH_X = 1, TFEM_SRC_PUSH_Y = 2, TFEM_SRC_PUSH_C = 3,
+  TFEM_SRC_ADD = 4, TFEM_SRC_SUB = 5, TFEM_SRC_SUB_R = 6, TFEM_SRC_MUL = 7,
+  TFEM_SRC_DIV = 8, TFEM_SRC_DIV_R = 9,
+  TFEM_SRC_ADD_C = 10, TFEM_SRC_MUL_C = 11, TFEM_SRC_RSUB_C = 12, TFEM_SRC_RDIV_C = 13,
+  TFEM_SRC_NEG = 14, TFEM_SRC_ABS = 15, TFEM_SRC_POW_I = 16,
+  TFEM_SRC_SIN = 17, TFEM_SRC_COS = 18, TFEM_SRC_EXP = 19, TFEM_SRC_SQRT = 20,
+  TFEM_SRC_LOG = 21, TFEM_SRC_TANH = 22,
+  TFEM_SRC_OP_COUNT = 23
+};
+typedef struct tfem_source_program {
+  int32_t n_ops;
+  int32_t reserved;
+  uint8_t ops[TFEM_SOURCE_MAX_OPS];
+  double consts[TFEM_SOURCE_MAX_OPS];
+} tfem_source_program;
+
+/* TFEM_OK when `program` (HOST) is a valid source program, TFEM_ERR_INVALID_ARGUMENT
+ * (tfem_last_error says why) otherwise. */
+int tfem_source_validate(const tfem_source_program *program);
+
+/* fq (n_elems, Q) = f at the integration points of every element (DEVICE; conn (n_elems, 3)
+ * vertex ids, `program` HOST): what the reference's callers compute with torch from
+ * basis.integration_points before multiplying by v (tests/test_assembly.py:79-84).  Feeds the
+ * entry points that take pre-evaluated source values (tfem_tri_load_vector,
+ * tfem_p1_assemble_tiles, P2) when the ring kernel does not apply. */
+int tfem_source_eval(const void *coords, int real_bytes, const void *conn, int idx_bytes,
+                     int64_t n_elems, int64_t n_verts, int quad_order,
+                     const tfem_source_program *program, void *fq, void *stream);
+
+/* tfem_p1_assemble_rings with the source values computed in the launch: the load vector
+ * fout[n_verts] = sum_e sum_q f(x_q) phi_i(x_q) dx_q of the program `source` (HOST), and, with
+ * vals != NULL, the CSR values of alpha * stiffness + beta * mass in the same launch.  The
+ * plan must carry the per-tile element vertex table (layout[20] != 0). */
+int tfem_p1_assemble_rings_source(const void *coords, int real_bytes, int64_t n_verts,
+                                  int quad_order, double alpha, double beta,
+                                  const void *plan_device, const int64_t *plan_layout_host,
+                                  void *vals, int64_t nnz, const tfem_source_program *source,
+                                  int64_t n_elems, void *fout, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * P2 row plan (HOST, once per mesh) + P2 row kernels (DEVICE): alpha * stiffness +

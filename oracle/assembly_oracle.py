@@ -243,6 +243,61 @@ def source_sin_sin(points):
     return 2.0 * math.pi**2 * np.sin(math.pi * x) * np.sin(math.pi * y)
 
 
+# op codes of include/tfem_assembly.h (enum tfem_source_op)
+SRC_PUSH_X, SRC_PUSH_Y, SRC_PUSH_C = 1, 2, 3
+SRC_ADD, SRC_SUB, SRC_SUB_R, SRC_MUL, SRC_DIV, SRC_DIV_R = 4, 5, 6, 7, 8, 9
+SRC_ADD_C, SRC_MUL_C, SRC_RSUB_C, SRC_RDIV_C = 10, 11, 12, 13
+SRC_NEG, SRC_ABS, SRC_POW_I = 14, 15, 16
+SRC_SIN, SRC_COS, SRC_EXP, SRC_SQRT, SRC_LOG, SRC_TANH = 17, 18, 19, 20, 21, 22
+
+
+def source_program_eval(ops, consts, x, y):
+    """CPU restatement of a source program (include/tfem_assembly.h, tfem_source_program): the
+    postfix form of the torch expressions a caller applies to the coordinate columns of
+    basis.integration_points before `* v` (tests/test_assembly.py:75-84); numpy arrays x, y of
+    one shape in, f of that shape out.  One numpy operation per program operation, in program
+    order -- the order the tracer recorded the caller's torch operations in."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    stack = []
+    unary = {SRC_NEG: np.negative, SRC_ABS: np.abs, SRC_SIN: np.sin, SRC_COS: np.cos, SRC_EXP: np.exp,
+             SRC_SQRT: np.sqrt, SRC_LOG: np.log, SRC_TANH: np.tanh}
+    for op, c in zip(ops, consts):
+        c = x.dtype.type(c)
+        if op == SRC_PUSH_X:
+            stack.append(x)
+        elif op == SRC_PUSH_Y:
+            stack.append(y)
+        elif op == SRC_PUSH_C:
+            stack.append(np.full_like(x, c))
+        elif op in (SRC_ADD, SRC_SUB, SRC_SUB_R, SRC_MUL, SRC_DIV, SRC_DIV_R):
+            hi = stack.pop()
+            lo = stack.pop()
+            stack.append({SRC_ADD: lambda: lo + hi, SRC_SUB: lambda: lo - hi, SRC_SUB_R: lambda: hi - lo,
+                          SRC_MUL: lambda: lo * hi, SRC_DIV: lambda: lo / hi, SRC_DIV_R: lambda: hi / lo}[op]())
+        elif op == SRC_ADD_C:
+            stack.append(stack.pop() + c)
+        elif op == SRC_MUL_C:
+            stack.append(stack.pop() * c)
+        elif op == SRC_RSUB_C:
+            stack.append(c - stack.pop())
+        elif op == SRC_RDIV_C:
+            stack.append(c / stack.pop())
+        elif op == SRC_POW_I:
+            t = stack.pop()
+            r = t * t
+            for _ in range(2, int(c)):
+                r = r * t
+            stack.append(r)
+        elif op in unary:
+            stack.append(unary[op](stack.pop()))
+        else:
+            raise ValueError(f"unknown source operation {op}")
+    if len(stack) != 1:
+        raise ValueError("the program leaves %d values" % len(stack))
+    return stack[0]
+
+
 def integrand_load(geo, source=source_sin_sin):
     """f(x_q) * v, tests/test_assembly.py:79-84."""
     return source(geo["integration_points"]) * geo["v"]

@@ -17,6 +17,23 @@ LIB_PATH = os.environ.get("TFEM_HIP_LIB") or os.path.join(_HERE, "csrc", "libtfe
 
 _lib = None
 
+#: TFEM_ABI_VERSION of include/tfem_assembly.h this binding was written against
+ABI_VERSION = 2
+
+#: tfem_source_program (include/tfem_assembly.h)
+SOURCE_MAX_OPS = 32
+SOURCE_STACK = 4
+
+
+class SourceProgram(ctypes.Structure):
+    _fields_ = [
+        ("n_ops", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("ops", ctypes.c_uint8 * SOURCE_MAX_OPS),
+        ("consts", ctypes.c_double * SOURCE_MAX_OPS),
+    ]
+
+
 #: every symbol include/tfem_assembly.h declares -> (restype, argtypes)
 SIGNATURES = {
     "tfem_abi_version": (c_int, []),
@@ -122,6 +139,16 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_void_p],
     ),
+    "tfem_source_validate": (c_int, [c_void_p]),
+    "tfem_source_eval": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p],
+    ),
+    "tfem_p1_assemble_rings_source": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
+         c_int64, c_void_p, c_int64, c_void_p, c_void_p],
+    ),
     "tfem_csr_to_dense": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p],
@@ -149,8 +176,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, surface it
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.tfem_abi_version() != 1:
-        raise NativeLibraryMissing(f"ABI version {lib.tfem_abi_version()} != 1; rebuild")
+    if lib.tfem_abi_version() != ABI_VERSION:
+        raise NativeLibraryMissing(f"ABI version {lib.tfem_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

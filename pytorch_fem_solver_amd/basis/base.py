@@ -30,6 +30,7 @@ class _LinearFormFunction(torch.autograd.Function):
     def forward(ctx, integrand, basis):
         ctx.basis = basis
         ctx.in_shape = integrand.shape
+        ctx.in_device = integrand.device
         return basis._engine.reduce_linear(integrand.detach(), basis._dx)
 
     @staticmethod
@@ -40,7 +41,28 @@ class _LinearFormFunction(torch.autograd.Function):
         lead = tuple(dx.shape[:-3])
         g = grad_out.reshape(-1)[conn].reshape(lead + (1, conn.shape[-1], 1))
         grad_integrand = g * dx
-        return grad_integrand.sum_to_size(ctx.in_shape), None
+        return grad_integrand.sum_to_size(ctx.in_shape).to(ctx.in_device), None
+
+
+class _FunctionalFunction(torch.autograd.Function):
+    """Differentiable per-element integral (abstract_basis.py:65-72): the reference's
+    ``(f * dx).sum(-3).sum(-2)`` stays in the autograd graph and is the training loss of
+    examples/example_loss_is_error.py:101-106, example_jump.py:147-151.  Forward: one
+    tfem_reduce_functional launch; backward: the cotangent of every element times dx."""
+
+    @staticmethod
+    def forward(ctx, integrand, basis):
+        ctx.basis = basis
+        ctx.in_shape = integrand.shape
+        ctx.in_device = integrand.device
+        return basis._engine.reduce_functional(integrand.detach(), basis._dx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dx = ctx.basis._dx.to(grad_out.device)  # (..., Q, 1, 1)
+        full = torch.broadcast_shapes(tuple(ctx.in_shape), tuple(dx.shape))
+        grad_integrand = (grad_out[..., None, None] * dx).expand(full)
+        return grad_integrand.sum_to_size(ctx.in_shape).to(ctx.in_device), None
 
 
 class AbstractBasis(abc.ABC):
@@ -108,9 +130,13 @@ class AbstractBasis(abc.ABC):
 
     # ---- integration API ---------------------------------------------------------------
     def integrate_functional(self, function, *args, **kwargs):
-        """Per-element integral of ``function(basis, ...)`` (abstract_basis.py:65-72)."""
-        integrand = function(self, *args, **kwargs)
-        out = self._engine.reduce_functional(integrand, self._dx)
+        """Per-element integral of ``function(basis, ...)`` (abstract_basis.py:65-72);
+        differentiable in the integrand."""
+        integrand = forms.materialize(forms.trace(function, self, args, kwargs))
+        if integrand.requires_grad and torch.is_grad_enabled():
+            out = _FunctionalFunction.apply(integrand, self)
+        else:
+            out = self._engine.reduce_functional(integrand.detach(), self._dx)
         return self._engine._home(out)
 
     def integrate_bilinear_form(self, function, *args, layout=None, **kwargs):
@@ -123,7 +149,13 @@ class AbstractBasis(abc.ABC):
         if isinstance(expr, forms.BilinearExpr):
             vals = self._engine.bilinear(expr.alpha, expr.beta)
         else:
-            integrand = function(self, *args, **kwargs)
+            integrand = forms.materialize(expr)
+            if integrand.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError(
+                    "integrate_bilinear_form: the integrand carries autograd history, but the "
+                    "assembled operator is written by the HIP kernels and is not differentiable; "
+                    "detach() the integrand, or differentiate a linear form / functional instead"
+                )
             vals = self._engine.reduce_bilinear(integrand, self._dx)
         matrix = self._engine.wrap_csr(vals)
         n = matrix.shape[0]
@@ -138,15 +170,23 @@ class AbstractBasis(abc.ABC):
     def integrate_linear_form(self, function, *args, **kwargs):
         """Global vector of a linear form, shape (N, 1) (abstract_basis.py:95-112)."""
         expr = forms.trace(function, self, args, kwargs)
-        if isinstance(expr, forms.LinearExpr) and not expr.coefficient.requires_grad:
-            coefficient = self._source_values(expr.coefficient)
-            if coefficient is not None:
-                return self._engine._home(self._engine.load(coefficient)).reshape(-1, 1)
-        integrand = function(self, *args, **kwargs)
-        if integrand.requires_grad:
+        if isinstance(expr, forms.LinearExpr) and expr.flux is None:
+            coefficient = expr.coefficient
+            if isinstance(coefficient, forms.SourceExpr):
+                # f(x, y) recorded by the tracer: evaluated inside the assembly launch
+                program = coefficient.program() if self._engine.supports_source() else None
+                if program is not None:
+                    return self._engine._home(self._engine.load_source(program)).reshape(-1, 1)
+                coefficient = coefficient.materialize()
+            if not coefficient.requires_grad:
+                values = self._source_values(coefficient)
+                if values is not None:
+                    return self._engine._home(self._engine.load(values)).reshape(-1, 1)
+        integrand = forms.materialize(expr)
+        if integrand.requires_grad and torch.is_grad_enabled():
             out = _LinearFormFunction.apply(integrand, self)
         else:
-            out = self._engine.reduce_linear(integrand, self._dx)
+            out = self._engine.reduce_linear(integrand.detach(), self._dx)
         return self._engine._home(out).reshape(-1, 1)
 
     def _source_values(self, coefficient):

@@ -178,6 +178,7 @@ def unpack_ring_plan(blob, layout):
         "vert_gid": view(3, np.int32, z[2]),
         "row_ecodes": np.frombuffer(blob, dtype=np.uint32, count=((12 * z[6] + 31) // 32) * z[1], offset=z[15]),
         "tile_elems": np.frombuffer(blob, dtype=np.int32, count=z[19], offset=z[16]),
+        "tile_tverts": np.frombuffer(blob, dtype=np.uint32, count=z[21], offset=z[20]),
         "elems_staged": bool(z[18]),
     }
 
@@ -443,6 +444,7 @@ class AssemblyEngine:
                         "layout": plan["layout"],
                         "chunked": plan["chunked"],
                         "elems_staged": plan["elems_staged"],
+                        "has_tverts": int(plan["layout"][21]) > 0 or int(plan["layout"][19]) == 0,
                         "rows_per_run": plan["rowstart"].size / n_runs,
                     }
             if self._rings is False and self.kernel == "rings":
@@ -639,30 +641,80 @@ class AssemblyEngine:
                              f"entries on {self.device}")
         return given.view(-1)
 
-    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True, out=(None, None)):
+    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True, out=(None, None), source=None):
         """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass and,
-        with source values fq (E, Q), the load vector (want_matrix=False: the vector alone)."""
+        with source values fq (E, Q) or a source program (evaluated in the launch), the load
+        vector (want_matrix=False: the vector alone)."""
         d = self._inputs()
         rings = self.ring_plan()
         nnz = int(self.csr_structure()[1].shape[0])
         # rows of vertices without elements are empty, every other entry is written once
         vals = self._output(out[0], nnz, "CSR values") if want_matrix else None
         fout = None
+        with_load = fq is not None or source is not None
         if fq is not None:
             fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
+        if with_load:
             fout = self._output(out[1], self.n_dofs, "load vector")
         with torch.cuda.device(self.device):
-            _native.check(
-                self.lib.tfem_p1_assemble_rings(
-                    _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
-                    float(alpha), float(beta), _native.ptr(rings["blob"]),
-                    c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
-                    _native.ptr(fq), self.n_elems, _native.ptr(fout), self._stream(),
+            if source is not None:
+                _native.check(
+                    self.lib.tfem_p1_assemble_rings_source(
+                        _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
+                        float(alpha), float(beta), _native.ptr(rings["blob"]),
+                        c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
+                        ctypes.byref(source), self.n_elems, _native.ptr(fout), self._stream(),
+                    )
                 )
-            )
+            else:
+                _native.check(
+                    self.lib.tfem_p1_assemble_rings(
+                        _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
+                        float(alpha), float(beta), _native.ptr(rings["blob"]),
+                        c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
+                        _native.ptr(fq), self.n_elems, _native.ptr(fout), self._stream(),
+                    )
+                )
         if not want_matrix:
             return fout
-        return (vals, fout) if fq is not None else vals
+        return (vals, fout) if with_load else vals
+
+    # ------------------------------------------------------------------ source programs
+    def supports_source(self):
+        """Source programs f(x, y) apply to one 2-D mesh (fracture points are 3-D)."""
+        return self.n_fractures == 0 and self._host_coords.dim() == 2
+
+    def _rings_take_source(self):
+        if self.kernel == "tiles" or not self._use_rings():
+            return False
+        rings = self.ring_plan()
+        return bool(rings["elems_staged"] and rings["has_tverts"])
+
+    def source_values(self, program):
+        """fq (E, Q) = the program at the integration points: one tfem_source_eval launch (for
+        the kernels that take pre-evaluated source values)."""
+        d = self._inputs()
+        fq = torch.empty((self.n_elems, self.n_quad), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self.lib.tfem_source_eval(
+                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]), 4,
+                    self.n_elems, self.coords_per_mesh, self.quad_order, ctypes.byref(program),
+                    _native.ptr(fq), self._stream(),
+                )
+            )
+        return fq
+
+    def load_source(self, program, out=None):
+        """(N_dof,) load vector of the source program: evaluated inside the ring launch where
+        the ring plan applies, else tfem_source_eval + the kernels that read source values."""
+        if self._rings_take_source():
+            return self._assemble_rings(0.0, 0.0, want_matrix=False, out=(None, out), source=program)
+        f = self.load(self.source_values(program))
+        if out is not None:
+            self._output(out, f.numel(), "load vector").copy_(f.view(-1))
+            return out
+        return f
 
     def _assemble_tiles(self, alpha, beta, want_matrix, fq):
         """One tfem_p1_assemble_tiles launch: CSR values and/or the load vector."""
@@ -687,10 +739,17 @@ class AssemblyEngine:
             )
         return vals, fout
 
-    def assemble_system(self, alpha, beta, fq, out=None):
+    def assemble_system(self, alpha, beta, fq=None, out=None, source=None):
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
-        values fq (E, Q): one fused launch on the ring and tile paths, two launches
-        otherwise.  ``out=(vals, f)``: write into these preallocated device buffers."""
+        values fq (E, Q) or of the source program `source`: one fused launch on the ring and
+        tile paths, two launches otherwise.  ``out=(vals, f)``: write into these preallocated
+        device buffers."""
+        if (fq is None) == (source is None):
+            raise ValueError("assemble_system: source values fq OR a source program")
+        if source is not None:
+            if self._rings_take_source():
+                return self._assemble_rings(alpha, beta, out=out or (None, None), source=source)
+            fq = self.source_values(source)
         if self._use_rings() and self.ring_plan()["elems_staged"]:
             return self._assemble_rings(alpha, beta, fq, out=out or (None, None))
         if self.tile_plan() is not None:

@@ -19,705 +19,9 @@
 // row records 8 B + halo vertex ids ~1 B + coordinates ~9.5 B (halo re-reads included) +
 // values 28.6 B = 47.6 B, against 48 B algorithmic: the 16-byte row records replace the
 // 24 bytes of connectivity the row's triangles take.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-
-#include "tfem_common.hpp"
-#include "tfem_rowkit.hpp"
-
-// Reassociation is harmless here (see above: the row form is not the reference's operation
-// order anyway; parity is asserted at 1e-12 against the oracle).
-#pragma clang fp contract(fast)
+#include "tfem_rings_kernel.hpp"
 
 namespace tfem {
-
-constexpr int kRingBlock = 256;             // lanes per workgroup = owned rows per tile
-constexpr int kRingWaves = kRingBlock / 64;
-constexpr int kRingVertCap = 1024;          // 10-bit local ids
-
-template <typename T>
-struct RingArgs {
-  const T *coords;
-  const unsigned char *plan;
-  T *vals;
-  const T *fq;  // (n_elems, Q) source values, load vector only
-  T *fout;
-  unsigned coords_bytes, plan_bytes, vals_bytes, fq_bytes, fout_bytes;
-  unsigned off_desc, off_rows, off_rowstart, off_gid, off_elems, off_telems;
-  int lds_elem;   // element slots reserved in LDS per buffer (load vector)
-  int xcd_interleave;  // 0: every XCD walks its own contiguous eighth of the tile list
-                       // G > 0: the tile list is dealt to the XCDs in blocks of G tiles (one
-                       //        front of tiles across the chip)
-  int n_tiles;
-  int lds_vert;   // vertex slots reserved in LDS
-  T stiff_w;      // alpha * sum_q w_q / 2
-  T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
-  T lamw[3][kMaxQuad];  // l_i(q) * w_q / 2 by local vertex i (load vector)
-  int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
-                  // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
-                  // source-value loads, 64 no element-id loads, 128 no g staging, 256 stamps
-  unsigned long long *stamps;  // ablation build, flag 256: 8 cycle sums per wave
-};
-
-// Ablation build only: shader-clock stamp (cdna_hip_programming.md section 7).
-__device__ __forceinline__ unsigned long long ring_stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-
-#ifndef TFEM_RING_BAND
-#define TFEM_RING_BAND 11
-#endif
-constexpr int kRingBand = TFEM_RING_BAND;  // short slot loop of the 15-slot kernels (0: none)
-
-// Field accessors of a row record (bit layout: tfem_rings_host.cpp).
-template <int SLOTS>
-struct RingRec {
-  static constexpr int kWords = SLOTS == 7 ? 4 : 8;
-  uint32_t w[kWords];
-  __device__ __forceinline__ uint32_t id(int i) const { return (w[i / 3] >> (10 * (i % 3))) & 0x3FFu; }
-  __device__ __forceinline__ int k() const {
-    return SLOTS == 7 ? int((w[0] >> 30) | (((w[1] >> 30) & 1u) << 2))
-                      : int((w[0] >> 30) | ((w[1] >> 30) << 2));
-  }
-  __device__ __forceinline__ int dpos() const {
-    return SLOTS == 7 ? int((w[2] >> 24) & 7u) : int((w[2] >> 30) | ((w[3] >> 30) << 2));
-  }
-  __device__ __forceinline__ uint32_t flag(int i) const {
-    return SLOTS == 7 ? (w[2] >> (10 + 2 * i)) & 3u : (w[SLOTS == 7 ? 0 : 5] >> (2 * i)) & 3u;
-  }
-  __device__ __forceinline__ int pos(int i) const {
-    if (SLOTS == 7) return int((w[3] >> (3 * i)) & 7u);
-    return i < 8 ? int((w[SLOTS == 7 ? 0 : 6] >> (4 * (i & 7))) & 15u)
-                 : int((w[SLOTS == 7 ? 0 : 7] >> (4 * (i & 7))) & 15u);
-  }
-};
-
-// The row of local vertex `lv`: entries of the neighbour slots in off[0 .. k), the diagonal in
-// diag (off[k ..] is scratch).  With q_i = |e_i|^2 and p = e_i.e_next the three entries of a
-// triangle are c (p - q_next), c (p - q_i) and their negative sum, c = +-W / (e_i x e_next); the
-// mass part adds det * M.  The triangle of slot i lands in off[i] and off[i + 1]; for the slot
-// that closes the fan (i + 1 == k) the second one belongs to slot 0 and is moved there at the
-// end (slots i >= k carry flag 0 and contribute nothing).  No branches: the reciprocal chains
-// of the slots interleave.
-// NIT < SLOTS: the caller knows that no row of the wave has more than NIT neighbours (the
-// 15-slot records of unstructured meshes: 11 slots cover ~94 % of the waves of a Delaunay mesh).
-template <typename T, int SLOTS, bool MASS, bool DETS, int NIT = SLOTS>
-__device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLOTS> &rec,
-                                         uint32_t lv, const T *xy, T (&off)[SLOTS + 1], T &diag,
-                                         T (&sdets)[SLOTS]) {
-  const int k = rec.k();
-  T xv, yv, px, py;
-  lds_xy(xy, lv, xv, yv);
-  const uint32_t id0 = rec.id(0);
-  lds_xy(xy, id0, px, py);
-  T ecx = px - xv, ecy = py - yv;
-  T qc = ecx * ecx + ecy * ecy;
-  T dsum = T(0);  // sum of the signed determinants around the vertex (mass part)
-#pragma unroll
-  for (int i = 0; i <= SLOTS; ++i) off[i] = T(0);
-  if (DETS) {
-#pragma unroll
-    for (int i = NIT; i < SLOTS; ++i) sdets[i] = T(0);
-  }
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    // neighbour behind slot i: slot i + 1, or slot 0 where the fan closes
-    const uint32_t idn = (i + 1 < SLOTS && i + 1 != k) ? rec.id(i + 1 < SLOTS ? i + 1 : 0) : id0;
-    lds_xy(xy, idn, px, py);
-    const T enx = px - xv, eny = py - yv;
-    const T qn = enx * enx + eny * eny;
-    const T p = ecx * enx + ecy * eny;
-    const T cross = ecx * eny - ecy * enx;  // +- the signed determinant (element_tri.py:139)
-    const uint32_t flag = rec.flag(i);      // 0 for every slot i >= k
-    const T cs = flag_weight<T>(a.stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
-    off[i] = off[i] + cs * (p - qn);
-    off[i + 1] = off[i + 1] + cs * (p - qc);
-    if (MASS || DETS) {
-      const T sdet = flag_weight<T>(T(1), flag) * cross;  // signed determinant, 0 without triangle
-      if (DETS) sdets[i] = sdet;
-      if (MASS) {
-        const T m = a.mass_o * sdet;
-        off[i] = off[i] + m;
-        off[i + 1] = off[i + 1] + m;
-        dsum = dsum + sdet;
-      }
-    }
-    ecx = enx;
-    ecy = eny;
-    qc = qn;
-  }
-  // the closing triangle's second entry sits in off[k]: it belongs to slot 0
-  T wrapv = off[1];
-#pragma unroll
-  for (int j = 2; j <= SLOTS; ++j) wrapv = k == j ? off[j] : wrapv;
-  // stiffness rows sum to zero (constants are in the kernel of the gradient): the diagonal is
-  // minus the sum of the off-diagonal stiffness entries; the mass part is added on top
-  T sum = off[0];
-#pragma unroll
-  for (int j = 1; j <= SLOTS; ++j) sum = sum + off[j];  // = sum_{j<k} off[j] + wrapv (once)
-  off[0] = off[0] + wrapv;
-  if (MASS) {
-    // the sum above holds stiffness AND off-diagonal mass (M_ij det, twice per triangle): take
-    // the mass out again before negating, then add the diagonal mass
-    diag = a.mass_d * dsum - (sum - T(2) * a.mass_o * dsum);
-  } else {
-    diag = -sum;
-  }
-}
-
-// Per-wave LDS stage: the wave's CSR entries, compact and in CSR order (row r of the wave
-// starts at the exclusive prefix sum of the row lengths).  Two spare entries behind the
-// 64 * (SLOTS + 1) real ones absorb the slots a row does not have, so staging has no branches.
-template <typename T, int SLOTS>
-constexpr int ring_stage_entries() { return 64 * (SLOTS + 1) + 2; }
-
-// Row entries -> the wave's stage (plain LDS stores).  `pre` = stage index of this lane's row;
-// returns the number of entries the wave staged (uniform).
-template <typename T, int SLOTS, int NIT = SLOTS>
-__device__ __forceinline__ int ring_stage(const RingRec<SLOTS> &rec, const T (&off)[SLOTS + 1], T diag,
-                                          T *stage, int &pre) {
-  const int k = rec.k();
-  const int len = k > 0 ? k + 1 : 0;
-  const int incl = wave_inclusive_scan(len);
-  pre = incl - len;
-  constexpr int kSpare = 64 * (SLOTS + 1);
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) stage[i < k ? pre + rec.pos(i) : kSpare] = off[i];
-  stage[k > 0 ? pre + rec.dpos() : kSpare] = diag;
-  return __builtin_amdgcn_readlane(incl, 63);
-}
-
-// The wave's stage -> global memory when the wave's rows form ONE run (a group of rows that is
-// contiguous in the CSR value array): stage index + delta = CSR index for the whole wave.
-// Lane j of step u takes entries 128 u + 2 j and the next one: 16-byte stores, 1 KiB
-// contiguous per wave instruction; whole steps need no per-lane test.  Every LDS read is
-// issued first (one LDS latency per tile).  Same wave as ring_stage: LDS executes a wave's
-// operations in order.
-template <typename T, int SLOTS, bool DBG = false>
-__device__ __forceinline__ void ring_store_run1(const T *stage, int total, int delta, ring_rsrc_t r_vals,
-                                                int flags = 0) {
-  const int lane = threadIdx.x & 63;
-  constexpr int kSteps = 64 * (SLOTS + 1) / 128;
-  T va[kSteps][2];
-#pragma unroll
-  for (int u = 0; u < kSteps; ++u) {
-    // 15-slot stage: rows hold ~7 of 16 entries, the steps behind `total` are skipped (uniform)
-    if (SLOTS > 7 && u >= 2 && 128 * u >= total) {
-      va[u][0] = va[u][1] = T(0);
-      continue;
-    }
-    va[u][0] = stage[128 * u + 2 * lane];
-    va[u][1] = stage[128 * u + 2 * lane + 1];
-  }
-#pragma unroll
-  for (int u = 0; u < kSteps; ++u) {
-    if (SLOTS > 7 && u >= 2 && 128 * u >= total) continue;
-    const int s0 = 128 * u + 2 * lane;
-    const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
-    const T v0 = va[u][0], v1 = va[u][1];
-    if (DBG && (flags & 1)) {
-      if (v0 == T(-1.2345e30) && v1 == v0) __builtin_amdgcn_raw_buffer_store_b32(0u, r_vals, byte, 0, 0);
-    } else if (128 * (u + 1) <= total || s0 + 1 < total) {  // first test is wave-uniform
-      if constexpr (sizeof(T) == 8) {
-        const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-        if (DBG && (flags & 1024))  // ablation: plain (temporal) stores
-          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
-        else
-          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, kStreamNT);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b64(
-            ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, kStreamNT);
-      }
-    } else if (s0 < total) {
-      if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, kStreamNT);
-      else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, kStreamNT);
-    }
-  }
-}
-
-// General form: the rows of a wave form several runs (one per grid line of a Z-order tile;
-// one per row for a numbering without locality).  Per run, as above.
-template <typename T, int SLOTS, bool DBG = false>
-__device__ __forceinline__ void ring_store(const T *stage, int total, int pre, int rowstart, int len,
-                                           ring_rsrc_t r_vals, int flags = 0) {
-  const int lane = threadIdx.x & 63;
-  __builtin_amdgcn_wave_barrier();
-  // A row starts a run when the rows since the previous non-empty row are not one contiguous
-  // piece of the CSR array.  `breaks` = lanes whose row does not begin where the row of lane
-  // r - 1 ends (wave_shr:1; rows without entries -- isolated vertices -- take part with their
-  // offset: an empty row between two pieces must not glue them together).
-  const int prev_end = __builtin_amdgcn_update_dpp(-1, rowstart + len, 0x138, 0xF, 0xF, false);
-  const unsigned long long has_row = __ballot(len > 0);
-  const unsigned long long breaks = __ballot(prev_end != rowstart);
-  const unsigned long long below = (1ull << lane) - 1ull;           // lanes < this one
-  const unsigned long long ne_below = has_row & below;
-  // lanes in (previous non-empty lane, this lane]
-  const unsigned long long since = ne_below ? ~((2ull << (63 - __builtin_clzll(ne_below))) - 1ull) : ~0ull;
-  const bool start = len > 0 && ((breaks & since & (below | (1ull << lane))) != 0ull || ne_below == 0ull);
-  unsigned long long starts = __ballot(start);
-  if ((starts & (starts - 1)) == 0) {
-    const int delta = starts ? __builtin_amdgcn_readlane(rowstart, __builtin_ctzll(starts)) : 0;
-    ring_store_run1<T, SLOTS, DBG>(stage, total, delta, r_vals, flags);
-    __builtin_amdgcn_wave_barrier();
-    return;
-  }
-  while (starts) {
-    const int r = __builtin_ctzll(starts);
-    starts &= starts - 1;
-    const int b = __builtin_amdgcn_readlane(pre, r);
-    const int delta = __builtin_amdgcn_readlane(rowstart, r) - b;
-    const int e = starts ? __builtin_amdgcn_readlane(pre, __builtin_ctzll(starts)) : total;
-    for (int s0 = b + 2 * lane; s0 - 2 * lane < e; s0 += 128) {
-      const T v0 = stage[s0], v1 = stage[s0 + 1];
-      const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
-      if (DBG && (flags & 1)) {
-        if (v0 == T(-1.2345e30) && v1 == v0) __builtin_amdgcn_raw_buffer_store_b32(0u, r_vals, byte, 0, 0);
-      } else if (s0 + 1 < e) {
-        if constexpr (sizeof(T) == 8) {
-          const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, kStreamNT);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b64(
-              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, kStreamNT);
-        }
-      } else if (s0 < e) {
-        if constexpr (sizeof(T) == 8)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, kStreamNT);
-        else
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, kStreamNT);
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int SLOTS>
-__device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, RingRec<SLOTS> &rec) {
-  const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte, 0, kStreamLoadNT);
-  rec.w[0] = v.x;
-  rec.w[1] = v.y;
-  rec.w[2] = v.z;
-  rec.w[3] = v.w;
-  if constexpr (SLOTS == 15) {
-    const ru32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte + 16u, 0, kStreamLoadNT);
-    rec.w[4] = u.x;
-    rec.w[5] = u.y;
-    rec.w[6] = u.z;
-    rec.w[7] = u.w;
-  }
-}
-
-// What one WAVE needs of a tile descriptor (20 ints, tfem_rings_host.cpp): the wave owns the
-// tile's rows [row0, row1), at most 64.  In a plan with consecutive-vertex tiles those rows
-// are the consecutive vertices gid0, gid0 + 1, ... and their CSR entries start at rs0: neither
-// the ids of the owned vertices nor the row offsets are read from memory.  Scalar loads with a
-// wave-uniform index (the plan is immutable during the launch: constant address space).
-struct RingDesc {
-  int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0, elem_off, n_elem, elem_mode;
-};
-constexpr int kRingElemRuns = 8;  // desc[18] = 1: the tile's elements are <= 8 runs of consecutive ids
-
-template <bool CHUNK>
-__device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigned off_desc, int tile,
-                                              int wave) {
-  ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 80u * unsigned(tile));
-  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17], d[18]};
-  if (CHUNK) {
-    r.gid0 = d[8 + wave];
-    r.rs0 = d[12 + wave];
-  }
-  return r;
-}
-
-// ---------------------------------------------------------------------------------------
-// Persistent, pipelined kernel: workgroups stay resident and walk a strided list of tiles
-// inside their XCD's piece of the curve (workgroup b: XCD b & 7, so every XCD -- own L2 --
-// walks one contiguous piece and neighbouring tiles share their halo coordinates in that L2).
-// Every lane owns one row; it also fetches the coordinates of its row's vertex and of one halo
-// vertex of the tile.  Iteration k (tile k: record and row offset in registers, coordinates in
-// xy[k & 1]):
-//   A  issue the loads of tile k+1 (row record, row offset, coordinates by the vertex ids that
-//      arrived during iteration k-1) and the vertex ids of tile k+2
-//   B  rows of tile k: LDS reads, arithmetic, entries -> the wave's stage
-//   C  s_waitcnt vmcnt(0): the loads of A were issued a whole row phase ago, the stores of
-//      tile k-1 a whole iteration ago
-//   D  coordinates of tile k+1 -> xy[(k+1) & 1]; stage -> global stores of tile k
-//   E  LDS barrier (the only one): xy[(k+1) & 1] is complete, nobody reads xy[k & 1] any more
-// Neither a load's latency nor a store's acknowledgement is waited for inside an iteration.
-// DBG = true is the ablation build of tools/time_rings.py (flags in RingArgs); its results are
-// wrong by design and the product path never uses it.
-// ---------------------------------------------------------------------------------------
-constexpr int kRingHaloCap = kRingBlock;  // halo vertices per tile: one per lane
-constexpr int kRingElemPerLane = 3;       // elements staged per tile <= 3 * kRingBlock
-
-__device__ __forceinline__ void ring_lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-#ifndef TFEM_NT_FQ
-#define TFEM_NT_FQ 0
-#endif
-constexpr int kFqLoadNT = TFEM_NT_FQ ? 2 : 0;
-// Q source values of one element (load vector): 16-byte loads where the type allows.
-template <typename T, int QL>
-__device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v)[QL > 0 ? QL : 1]) {
-#pragma unroll
-  for (int q = 0; q + 1 < QL; q += 2) {
-    if constexpr (sizeof(T) == 8) {
-      const ru32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, byte + unsigned(q) * 8u, 0, kFqLoadNT);
-      v[q] = __builtin_bit_cast(double, ru32x2{x.x, x.y});
-      v[q + 1] = __builtin_bit_cast(double, ru32x2{x.z, x.w});
-    } else {  // two dword loads: raw_buffer_load_b64 is miscompiled by this hipcc (tfem_tiles.hip)
-      v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte + unsigned(q) * 4u, 0, 0));
-      v[q + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte + unsigned(q) * 4u + 4u, 0, 0));
-    }
-  }
-  if (QL & 1) {
-    const unsigned o = byte + unsigned(QL - 1) * unsigned(sizeof(T));
-    if constexpr (sizeof(T) == 8) {
-      const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0);
-      const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(r, o + 4u, 0, 0);
-      v[QL > 0 ? QL - 1 : 0] = __builtin_bit_cast(double, ru32x2{lo, hi});
-    } else {
-      v[QL > 0 ? QL - 1 : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 0));
-    }
-  }
-}
-
-// QL = 0: matrix only.  QL = Q > 0: the launch also forms the load vector
-//   f_v = sum over the triangles T of the fan  det_T * g[T][loc],
-//   g[T][i] = sum_q fq[T][q] l_i(q) w_q / 2
-// (abstract_basis.py:95-112 with basis.py:93-96).  The source values of a tile's elements
-// (plan: tile_elems, ascending) are fetched ONCE per tile with coalesced 16-byte loads -- three
-// elements per lane, prefetched like the coordinates -- reduced to the three numbers g[T][.]
-// and staged in LDS; a row reads one of them per fan slot by the slot's
-// 12-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
-// instead is bound by the texture addresser: 14 scattered loads per row.)
-template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true>
-// The matrix-only 15-slot instantiations are asked for 3 waves per SIMD: left alone, hipcc's
-// scheduler hoists every LDS read of the unrolled fan loop and ends at 250 VGPRs (2 waves); with
-// the bound it needs 112-128 and nothing spills (the load-vector instantiations would spill).
-__global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_p1_rings(const RingArgs<T> a) {
-  constexpr bool LOAD = QL > 0;
-  static_assert(KMAT || LOAD, "nothing to assemble");
-  constexpr int kEW = (12 * SLOTS + 31) / 32;  // dwords of packed 12-bit slot codes per row: 3 or 6
-  extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
-  T *xy = reinterpret_cast<T *>(ring_smem);                      // [2][2 * lds_vert]
-  T *stage = xy + 4 * a.lds_vert;                                // [waves][stage entries]
-  // [3 * lds_elem + 4]; the load-vector-only instantiation has no stage
-  T *gtab = stage + (KMAT ? kRingWaves * ring_stage_entries<T, SLOTS>() : 0);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  T *my_stage = stage + wave * ring_stage_entries<T, SLOTS>();
-  // tiles per XCD, a whole number of blocks when the tile list is dealt in blocks
-  const int deal = a.xcd_interleave > 0 ? a.xcd_interleave : 1;
-  const int per = (a.n_tiles + 8 * deal - 1) / (8 * deal) * deal;
-  const int xcd = blockIdx.x & 7;
-  const int j0 = blockIdx.x >> 3;
-  const int stride = gridDim.x >> 3;
-  auto tile_at = [&](int k) {
-    const int j = j0 + k * stride;
-    const int g = a.xcd_interleave;
-    const int t = g ? ((j / g) * 8 + xcd) * g + j % g : xcd * per + j;
-    return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
-  };
-  const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
-  const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
-  const ring_rsrc_t r_vals = ring_rsrc(a.vals, a.vals_bytes);
-  const ring_rsrc_t r_fq = ring_rsrc(a.fq, a.fq_bytes);
-  const ring_rsrc_t r_fout = ring_rsrc(a.fout, a.fout_bytes);
-  constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
-  constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
-  if (LOAD && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
-    gtab[3 * a.lds_elem + tid] = T(0);
-
-  RingRec<SLOTS> rec, rec_ld;
-  uint32_t se[LOAD ? kEW : 1], se_ld[LOAD ? kEW : 1];  // slot codes of the row (load vector)
-  unsigned eid[LOAD ? kRingElemPerLane : 1], eid_ld[LOAD ? kRingElemPerLane : 1];  // element ids, like gid_*
-  T fqe_ld[LOAD ? kRingElemPerLane : 1][QL > 0 ? QL : 1];  // their source values
-  unsigned gid_row = 0;                                    // vertex of this lane's current row
-  int rowstart = 0, rowstart_ld = 0;
-  unsigned gid_own = 0, gid_halo = 0;        // vertex ids of the tile whose coordinates load next
-  unsigned gid_own_ld = 0, gid_halo_ld = 0;  // ... and of the tile after it
-  T own_ld[2], halo_ld[2];
-
-  // vertex ids of a tile: the lane's own row vertex and halo vertex number tid.  With
-  // consecutive-vertex tiles the own id is arithmetic on the descriptor.
-  auto load_ids = [&](const RingDesc &d, unsigned &g_own, unsigned &g_halo) {
-    const int r = d.row0 + lane;
-    if (CHUNK)
-      g_own = unsigned(d.gid0 + lane);
-    else
-      g_own = __builtin_amdgcn_raw_buffer_load_b32(
-          r_plan, a.off_gid + (r < d.row1 ? unsigned(d.vert_off + r) : kNone) * 4u, 0, 0);
-    const int h = d.n_own + tid;
-    g_halo = __builtin_amdgcn_raw_buffer_load_b32(
-        r_plan, a.off_gid + (h < d.n_vert ? unsigned(d.vert_off + h) : kNone) * 4u, 0, 0);
-  };
-  auto load_eids = [&](const RingDesc &d, unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
-    if (!LOAD || (DBG && (a.flags & 64))) return;  // ablation: no element-id loads
-    if (d.elem_mode) return;                        // runs of consecutive ids: nothing to fetch
-#pragma unroll
-    for (int j = 0; j < kRingElemPerLane; ++j) {
-      const int l = tid + j * kRingBlock;
-      e[LOAD ? j : 0] = __builtin_amdgcn_raw_buffer_load_b32(
-          r_plan, a.off_telems + (l < d.n_elem ? unsigned(d.elem_off + l) : kNone) * 4u, 0, 0);
-    }
-  };
-  // source values of the tile's elements by the ids that arrived an iteration earlier (lanes
-  // past the tile's last element carry the id 0 of the zero-filled load: harmless)
-  auto load_fq = [&](const RingDesc &d, const unsigned (&e)[LOAD ? kRingElemPerLane : 1]) {
-    if (!LOAD || (DBG && (a.flags & 32))) return;  // ablation: no source-value loads
-    if (d.elem_mode) {
-      // position l in the tile's ascending element list -> id, from the first ids of the runs
-      // and the list positions they end at (16 scalars of the plan)
-      ring_const_i32 rg = (ring_const_i32)(uintptr_t)(a.plan + a.off_telems + 4u * unsigned(d.elem_off));
-      int first[kRingElemRuns], upto[kRingElemRuns];
-#pragma unroll
-      for (int r = 0; r < kRingElemRuns; ++r) {
-        first[r] = rg[r];
-        upto[r] = rg[kRingElemRuns + r];
-      }
-#pragma unroll
-      for (int j = 0; j < kRingElemPerLane; ++j) {
-        const int l = tid + j * kRingBlock;
-        int id = first[0] + l;
-#pragma unroll
-        for (int r = 1; r < kRingElemRuns; ++r) id = l >= upto[r - 1] ? first[r] + (l - upto[r - 1]) : id;
-        ring_load_fq<T, QL>(r_fq, l < d.n_elem ? unsigned(id) * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u,
-                            fqe_ld[LOAD ? j : 0]);
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < kRingElemPerLane; ++j) {
-      const int l = tid + j * kRingBlock;
-      ring_load_fq<T, QL>(r_fq, l < d.n_elem ? e[LOAD ? j : 0] * unsigned(QL * sizeof(T)) : 0xFFFFFFF0u,
-                          fqe_ld[LOAD ? j : 0]);
-    }
-  };
-  // g[T][i] = sum_q fq[T][q] l_i(q) w_q / 2 of the elements just loaded -> LDS
-  auto park_g = [&](const RingDesc &d, T *dst) {
-    if (!LOAD || (DBG && (a.flags & 128))) return;  // ablation: no reduction / staging of g
-#pragma unroll
-    for (int j = 0; j < kRingElemPerLane; ++j) {
-      const int l = tid + j * kRingBlock;
-      if (l < d.n_elem) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          T g = T(0);
-#pragma unroll
-          for (int q = 0; q < QL; ++q) g = g + fqe_ld[LOAD ? j : 0][q] * a.lamw[i][q];
-          dst[3 * l + i] = g;
-        }
-      }
-    }
-  };
-  auto load_tile = [&](const RingDesc &d, unsigned g_own, unsigned g_halo) {
-    const int r = d.row0 + lane;
-    const unsigned row = r < d.row1 ? unsigned(d.row_off + r) : kNone;
-    if (!(DBG && (a.flags & 16))) {
-      ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
-      if (!CHUNK)
-        rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
-      if (LOAD) {  // 12-bit slot codes: 3 (SLOTS 7) or 6 dwords per row
-        const unsigned eb = a.off_elems + row * unsigned(4 * kEW);
-#pragma unroll
-        for (int i = 0; i < kEW; i += 3) {
-          const ru32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r_plan, eb + unsigned(4 * i), 0, kStreamLoadNT);
-          se_ld[LOAD ? i : 0] = v.x;
-          se_ld[LOAD ? i + 1 : 0] = v.y;
-          se_ld[LOAD ? i + 2 : 0] = v.z;
-        }
-      }
-    }
-    if (!(DBG && (a.flags & 4))) {
-      ring_load_xy<T>(r_coords, g_own, own_ld[0], own_ld[1]);
-      ring_load_xy<T>(r_coords, g_halo, halo_ld[0], halo_ld[1]);
-    }
-  };
-  auto park = [&](const RingDesc &d, T *dst) {
-    const int r = d.row0 + lane;
-    if (r < d.row1) {
-      dst[2 * r] = own_ld[0];
-      dst[2 * r + 1] = own_ld[1];
-    }
-    const int h = d.n_own + tid;
-    if (h < d.n_vert) {
-      dst[2 * h] = halo_ld[0];
-      dst[2 * h + 1] = halo_ld[1];
-    }
-  };
-
-  int t_c = tile_at(0);
-  if (t_c < 0) return;  // whole workgroup, before any barrier
-  int t_n = tile_at(1), t_nn = tile_at(2);
-  RingDesc dc = ring_desc<CHUNK>(a.plan, a.off_desc, t_c, wave);
-  RingDesc dn = ring_desc<CHUNK>(a.plan, a.off_desc, t_n >= 0 ? t_n : t_c, wave);
-  RingDesc dnn = ring_desc<CHUNK>(a.plan, a.off_desc, t_nn >= 0 ? t_nn : t_c, wave);
-  // prologue: tile 0 taken over, vertex ids of tile 1 in registers
-  load_ids(dc, gid_own, gid_halo);
-  load_eids(dc, eid);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  load_tile(dc, gid_own, gid_halo);
-  load_fq(dc, eid);
-  if (t_n >= 0) {
-    load_ids(dn, gid_own_ld, gid_halo_ld);
-    load_eids(dn, eid_ld);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  park(dc, xy);
-  park_g(dc, gtab);
-  rec = rec_ld;
-  rowstart = rowstart_ld;
-  gid_row = gid_own;
-#pragma unroll
-  for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
-#pragma unroll
-  for (int j = 0; j < (LOAD ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
-  gid_own = gid_own_ld;
-  gid_halo = gid_halo_ld;
-  __syncthreads();
-
-  int cur = 0;
-  const bool timing = DBG && (a.flags & 256);
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int k = 0;; ++k) {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
-    if (timing) t0 = ring_stamp();
-    // ---- A ----
-    if (t_n >= 0) {
-      load_tile(dn, gid_own, gid_halo);
-      load_fq(dn, eid);
-      if (t_nn >= 0) {
-        load_ids(dnn, gid_own_ld, gid_halo_ld);
-        load_eids(dnn, eid_ld);
-      }
-    }
-    if (timing) t1 = ring_stamp();
-    // ---- B ----
-    T off[SLOTS + 1], diag, sdets[SLOTS];
-    // wave-uniform: shorter slot loops when no row of this wave needs the long ones
-    constexpr int kBandSlots = (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : SLOTS;
-    const bool banded = kBandSlots < SLOTS && __builtin_amdgcn_ballot_w64(rec.k() > kBandSlots) == 0;
-    if (!(DBG && (a.flags & 2))) {
-      const int my_row = dc.row0 + lane;
-      const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
-      if (banded)
-        ring_row<T, SLOTS, MASS, LOAD, kBandSlots>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
-      else
-        ring_row<T, SLOTS, MASS, LOAD>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
-    } else {
-      diag = T(1);
-#pragma unroll
-      for (int i = 0; i <= SLOTS; ++i) off[i] = T(i);
-    }
-    if (timing) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      t2 = ring_stamp();
-    }
-    int total = 0, pre = 0;
-    if (KMAT && !(DBG && (a.flags & 8)))
-      total = banded ? ring_stage<T, SLOTS, kBandSlots>(rec, off, diag, my_stage, pre)
-                     : ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
-    T facc = T(0);
-    if (LOAD) {
-      const T *g = gtab;
-#pragma unroll
-      for (int i = 0; i < SLOTS; ++i) {
-        // code: tile-local element | loc << 10; 0xFFF (no triangle) reads the spare entries
-        // behind the table, its determinant is 0
-        const int bit = 12 * i, w0 = bit / 32, sh = bit % 32;  // constants once the loop is unrolled
-        const uint32_t lo = se[w0] >> sh;
-        const uint32_t code = (sh > 20 ? lo | (se[w0 + 1 < kEW ? w0 + 1 : w0] << (32 - sh)) : lo) & 0xFFFu;
-        const uint32_t at = code == 0xFFFu ? unsigned(3 * a.lds_elem) : 3u * (code & 0x3FFu) + (code >> 10);
-        facc = facc + sdets[i] * g[at];
-      }
-    }
-    const int kk = rec.k();
-    const int len_c = kk > 0 ? kk + 1 : 0;
-    if (timing) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      t3 = ring_stamp();
-    }
-    // ---- C ----
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); the builtin, so that hipcc's own wait
-                                         // insertion knows the loads have landed
-    if (timing) t4 = ring_stamp();
-    // ---- D ----
-    if (t_n >= 0) {
-      park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
-      if (LOAD) {
-        // the element table is single-buffered (LDS for a third workgroup per CU): every wave
-        // has read tile k's entries (the loop above) before anybody overwrites them
-        ring_lds_barrier();
-        park_g(dn, gtab);
-      }
-    }
-    if (timing) t5 = ring_stamp();
-    if (KMAT && !(DBG && (a.flags & 8))) {
-      if (CHUNK) {  // one run per wave by construction, its CSR offset in the descriptor
-        __builtin_amdgcn_wave_barrier();
-        ring_store_run1<T, SLOTS, DBG>(my_stage, total, dc.rs0, r_vals, a.flags);
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        ring_store<T, SLOTS, DBG>(my_stage, total, pre, rowstart, len_c, r_vals, a.flags);
-      }
-    }
-    if (LOAD && dc.row0 + lane < dc.row1) {
-      const unsigned byte = gid_row * unsigned(sizeof(T));
-      if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, facc), r_fout, byte, 0, kStreamNT);
-      else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, facc), r_fout, byte, 0, kStreamNT);
-    }
-    if (timing) {
-      t6 = ring_stamp();
-      tsum[0] += t1 - t0;  // A load issue
-      tsum[1] += t2 - t1;  // B rows
-      tsum[2] += t3 - t2;  // stage
-      tsum[3] += t4 - t3;  // vmcnt(0)
-      tsum[4] += t5 - t4;  // park
-      tsum[5] += t6 - t5;  // stores
-      tsum[7] += 1;
-    }
-    if (t_n < 0) break;
-    rec = rec_ld;
-    rowstart = rowstart_ld;
-    gid_row = gid_own;
-#pragma unroll
-    for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
-#pragma unroll
-    for (int j = 0; j < (LOAD ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
-    gid_own = gid_own_ld;
-    gid_halo = gid_halo_ld;
-    // ---- E ----
-    ring_lds_barrier();
-    if (timing) {
-      t7 = ring_stamp();
-      tsum[6] += t7 - t6;  // barrier (and the register hand-over)
-    }
-    t_c = t_n;
-    dc = dn;
-    t_n = t_nn;
-    dn = dnn;
-    t_nn = tile_at(k + 3);
-    if (t_nn >= 0) dnn = ring_desc<CHUNK>(a.plan, a.off_desc, t_nn, wave);
-    cur ^= 1;
-  }
-  if (timing && a.stamps && lane == 0) {
-    unsigned long long *o = a.stamps + 8 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
-    for (int i = 0; i < 8; ++i) o[i] = tsum[i];
-  }
-}
 
 struct RingLaunch {
   const void *coords;
@@ -731,6 +35,7 @@ struct RingLaunch {
   const void *fq = nullptr;  // nullptr: no load vector
   int64_t n_elems = 0;
   void *fout = nullptr;
+  const tfem_source_program *source = nullptr;  // load vector of this program instead of fq
   int blocks_per_cu = 0;  // > 0: cap on resident workgroups per CU (tuning)
   int flags = 0;          // > 0: ablation build (wrong results by design)
   unsigned long long *stamps = nullptr;
@@ -773,17 +78,20 @@ static void *pick_ring_q(int nq) {
   }
 }
 
-template <typename T, int SLOTS, bool MASS>
-static void *pick_ring_chunk(bool chunk, int nq) {
-  return chunk ? pick_ring_q<T, SLOTS, MASS, true>(nq) : pick_ring_q<T, SLOTS, MASS, false>(nq);
+template <typename T, int SLOTS, bool CHUNK>
+static void *pick_ring_mass(bool kmat, bool mass, int nq) {
+  if (!kmat) return pick_ring_load_only<T, SLOTS, CHUNK>(nq);
+  return mass ? pick_ring_q<T, SLOTS, true, CHUNK>(nq) : pick_ring_q<T, SLOTS, false, CHUNK>(nq);
 }
 
-// nq = 0: matrix only
+// nq = 0: matrix only; kmat = false: the load vector alone; src: source program in the launch
+// (those instantiations live in tfem_rings_src.hip)
 template <typename T>
-static void *pick_ring_kernel(int slots, bool mass, bool chunk, int nq) {
+static void *pick_ring_kernel(int slots, bool mass, bool chunk, int nq, bool src, bool kmat) {
+  if (src) return pick_ring_src_kernel<T>(slots, mass, chunk, nq, kmat);
   if (slots == 7)
-    return mass ? pick_ring_chunk<T, 7, true>(chunk, nq) : pick_ring_chunk<T, 7, false>(chunk, nq);
-  return mass ? pick_ring_chunk<T, 15, true>(chunk, nq) : pick_ring_chunk<T, 15, false>(chunk, nq);
+    return chunk ? pick_ring_mass<T, 7, true>(kmat, mass, nq) : pick_ring_mass<T, 7, false>(kmat, mass, nq);
+  return chunk ? pick_ring_mass<T, 15, true>(kmat, mass, nq) : pick_ring_mass<T, 15, false>(kmat, mass, nq);
 }
 
 template <typename T>
@@ -793,8 +101,10 @@ static int launch_rings(const RingLaunch &L) {
     return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   const int64_t *z = L.layout;
   if (z[0] == 0) return TFEM_OK;
-  const bool load = L.fq != nullptr;
+  const bool src = L.source != nullptr;
+  const bool load = L.fq != nullptr || src;
   const bool kmat = L.vals != nullptr;
+  if (src && L.fq) return fail(TFEM_ERR_INVALID_ARGUMENT, "source values AND a source program");
   if (!kmat && !load) return fail(TFEM_ERR_INVALID_ARGUMENT, "nothing to assemble");
   if (!L.coords || !L.plan || (load && !L.fout)) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] || z[14] > kRingHaloCap ||
@@ -807,7 +117,7 @@ static int launch_rings(const RingLaunch &L) {
   a.vals = static_cast<T *>(L.vals);
   const int64_t rb = int64_t(sizeof(T));
   const int64_t extents[5] = {L.n_verts * 2 * rb, z[12], kmat ? L.nnz * rb : 0,
-                              load ? L.n_elems * tables.nq * rb : 0, load ? L.n_verts * rb : 0};
+                              (load && !src) ? L.n_elems * tables.nq * rb : 0, load ? L.n_verts * rb : 0};
   for (int64_t e : extents)
     if (e < 0 || e >= (int64_t(1) << 32))
       return fail(TFEM_ERR_INDEX_RANGE, "an array of %lld bytes does not fit the 32-bit offsets "
@@ -832,7 +142,17 @@ static int launch_rings(const RingLaunch &L) {
     return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan has %lld elements: the fused load "
                 "vector stages at most %d", (long long)z[17], kRingElemPerLane * kRingBlock);
   for (int i = 0; i < 3; ++i)
-    for (int q = 0; q < tables.nq; ++q) a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
+    for (int q = 0; q < tables.nq; ++q) {
+      a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
+      a.lam[i][q] = T(tables.lam[q][i]);
+    }
+  if (src) {
+    if (z[20] == 0 || z[21] == 0)
+      return fail(TFEM_ERR_UNSUPPORTED, "the ring plan carries no element vertex table (source programs)");
+    a.off_tverts = unsigned(z[20]);
+    const int st = src_convert<T>(L.source, &a.src);
+    if (st != TFEM_OK) return st;
+  }
   a.off_desc = unsigned(z[8]);
   a.off_rows = unsigned(z[9]);
   a.off_rowstart = unsigned(z[10]);
@@ -860,13 +180,10 @@ static int launch_rings(const RingLaunch &L) {
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
-  void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0);
-  if (!kmat)
-    kernel = slots == 7 ? (chunk ? pick_ring_load_only<T, 7, true>(tables.nq) : pick_ring_load_only<T, 7, false>(tables.nq))
-                        : (chunk ? pick_ring_load_only<T, 15, true>(tables.nq) : pick_ring_load_only<T, 15, false>(tables.nq));
+  void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0, src, kmat);
   if (!kernel) return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   if constexpr (sizeof(T) == 8) {  // the ablation build exists for fp64 stiffness, 7 slots
-    if (kmat && L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {
+    if (kmat && !src && L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {
       if (load)
         kernel = chunk ? reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 4, true>)
                        : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, 4, true>);
@@ -923,6 +240,24 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
   // developer switches (tools/time_rings.py)
   if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
   if (const char *v = std::getenv("TFEM_RINGS_DEBUG")) L.flags = std::atoi(v);  // ablation build
+  return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
+}
+
+int tfem_p1_assemble_rings_source(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                                  double alpha, double beta, const void *plan_device,
+                                  const int64_t *plan_layout_host, void *vals, int64_t nnz,
+                                  const tfem_source_program *source, int64_t n_elems, void *fout,
+                                  void *stream) {
+  using namespace tfem;
+  if (real_bytes != 4 && real_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (!plan_layout_host || !source) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  RingLaunch L{coords, quad_order, alpha, beta, static_cast<const unsigned char *>(plan_device),
+               plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
+  L.source = source;
+  L.n_elems = n_elems;
+  L.fout = fout;
+  if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
   return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
 }
 

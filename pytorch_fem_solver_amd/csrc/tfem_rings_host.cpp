@@ -47,7 +47,8 @@ struct RingPlan {
   // per tile (20 ints): vert_off, n_vert, row_off, then start_0 = 0, start_1, start_2, start_3,
   // start_4 = n_own (wave w of the workgroup owns the tile's rows [start_w, start_{w+1})),
   // global id of the first row of wave 0..3, CSR offset of the first row of wave 0..3,
-  // offset into tile_elems, number of elements of the tile, 0, 0
+  // offset into tile_elems, number of elements of the tile, element-list mode, offset into
+  // tile_tverts
   std::vector<int32_t> desc;
   std::vector<uint32_t> rows;     // `words` dwords per owned row
   std::vector<int32_t> rowstart;  // rowptr[g] of every owned row
@@ -57,6 +58,10 @@ struct RingPlan {
   // of the row's vertex in that element << 10 (0xFFF: no triangle); 12 bits per slot, packed.
   std::vector<int32_t> tile_elems;
   std::vector<uint32_t> row_ecodes;
+  // per tile element (order of the tile's ascending element list): the three tile-local vertex
+  // ids of the element in its own local order, 10 bits each -- what the kernel needs to form the
+  // integration points of the element from the coordinates it holds in LDS (source programs)
+  std::vector<uint32_t> tile_tverts;
   int32_t max_n_elem = 0;
   bool elems_staged = true;  // false: some tile has more than kRingElemCap elements
   std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
@@ -333,6 +338,12 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     std::sort(elems_here.begin(), elems_here.end());
     const int32_t elem_off = int32_t(plan.tile_elems.size());
     const int32_t n_elem = int32_t(elems_here.size());
+    const int32_t tvert_off = int32_t(plan.tile_tverts.size());
+    for (int32_t j = 0; j < n_elem; ++j) {
+      const I *c = conn + 3 * int64_t(elems_here[size_t(j)]);
+      plan.tile_tverts.push_back(uint32_t(vert_local[size_t(c[0])]) | uint32_t(vert_local[size_t(c[1])]) << 10 |
+                                 uint32_t(vert_local[size_t(c[2])]) << 20);
+    }
     if (n_elem > kRingElemCap) plan.elems_staged = false;
     for (int32_t j = 0; j < n_elem; ++j) elem_local[size_t(elems_here[size_t(j)])] = j;
     // Element numberings with locality: the ascending list is a few runs of consecutive ids.
@@ -379,7 +390,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     }
     int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
                                   wave_start[1], wave_start[2], wave_start[3], n_own,
-                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, elem_mode, 0};
+                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, elem_mode, tvert_off};
     plan.max_n_halo = std::max(plan.max_n_halo, next_local - n_own);
     for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
       if (wave_start[w] < wave_start[w + 1]) {
@@ -396,6 +407,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.rows.clear();
     plan.rowstart.clear();
     plan.tile_elems.clear();
+    plan.tile_tverts.clear();
     plan.row_ecodes.clear();
     plan.max_n_elem = 0;
     plan.elems_staged = true;
@@ -574,12 +586,13 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[6] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+  const int64_t bytes[7] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
                             int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
-                            int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4};
-  const int slot_of[6] = {8, 9, 10, 11, 15, 16};
+                            int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4,
+                            int64_t(p.tile_tverts.size()) * 4};
+  const int slot_of[7] = {8, 9, 10, 11, 15, 16, 20};
   int64_t off = 0;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 7; ++i) {
     layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
@@ -587,6 +600,7 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[17] = p.max_n_elem;
   layout[18] = p.elems_staged ? 1 : 0;
   layout[19] = int64_t(p.tile_elems.size());
+  layout[21] = int64_t(p.tile_tverts.size());
   layout[13] = p.chunked ? 1 : 0;
   layout[14] = p.max_n_halo;
 }
@@ -650,6 +664,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   std::memcpy(out + layout[11], p->vert_gid.data(), p->vert_gid.size() * 4);
   std::memcpy(out + layout[15], p->row_ecodes.data(), p->row_ecodes.size() * 4);
   std::memcpy(out + layout[16], p->tile_elems.data(), p->tile_elems.size() * 4);
+  std::memcpy(out + layout[20], p->tile_tverts.data(), p->tile_tverts.size() * 4);
   return TFEM_OK;
 }
 

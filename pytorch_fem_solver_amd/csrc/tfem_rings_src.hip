@@ -1,0 +1,51 @@
+// The instantiations of k_p1_rings (tfem_rings_kernel.hpp) that evaluate a source program in
+// the launch (SRC = true).  A translation unit of its own because it is built with
+// `-mllvm -disable-machine-licm` (__graft_entry__.py): inside the interpreter loop of
+// tfem_source.hpp hipcc's machine-level loop-invariant code motion hoists the materialisation of
+// every floating-point literal of every operation (polynomial coefficients of sin, cos, exp,
+// log ...) out of the loop and keeps them all in registers at once -- 114 VGPRs for a ONE-point
+// interpreter against 38 without the pass; the fused launch would drop from 3 to 2 workgroups
+// per CU.  The other kernels keep the default pipeline.
+#include "tfem_rings_kernel.hpp"
+
+namespace tfem {
+
+template <typename T, int SLOTS, bool CHUNK>
+static void *pick_src_load_only(int nq) {
+  switch (nq) {
+    case 1: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 1, false, false, true>);
+    case 3: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 3, false, false, true>);
+    case 4: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 4, false, false, true>);
+    case 6: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, false, CHUNK, 6, false, false, true>);
+    default: return nullptr;
+  }
+}
+
+template <typename T, int SLOTS, bool MASS, bool CHUNK>
+static void *pick_src_q(int nq) {
+  switch (nq) {
+    case 1: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 1, false, true, true>);
+    case 3: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 3, false, true, true>);
+    case 4: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 4, false, true, true>);
+    case 6: return reinterpret_cast<void *>(k_p1_rings<T, SLOTS, MASS, CHUNK, 6, false, true, true>);
+    default: return nullptr;
+  }
+}
+
+template <typename T, int SLOTS, bool CHUNK>
+static void *pick_src_mass(bool kmat, bool mass, int nq) {
+  if (!kmat) return pick_src_load_only<T, SLOTS, CHUNK>(nq);
+  return mass ? pick_src_q<T, SLOTS, true, CHUNK>(nq) : pick_src_q<T, SLOTS, false, CHUNK>(nq);
+}
+
+template <typename T>
+void *pick_ring_src_kernel(int slots, bool mass, bool chunk, int nq, bool kmat) {
+  if (slots == 7)
+    return chunk ? pick_src_mass<T, 7, true>(kmat, mass, nq) : pick_src_mass<T, 7, false>(kmat, mass, nq);
+  return chunk ? pick_src_mass<T, 15, true>(kmat, mass, nq) : pick_src_mass<T, 15, false>(kmat, mass, nq);
+}
+
+template void *pick_ring_src_kernel<double>(int, bool, bool, int, bool);
+template void *pick_ring_src_kernel<float>(int, bool, bool, int, bool);
+
+}  // namespace tfem

@@ -1,0 +1,233 @@
+// Source programs: the user's f(x, y) of a linear form `f(x_q) * v` (abstract_basis.py:95-112,
+// tests/test_assembly.py:75-84) as a short postfix program, evaluated INSIDE the assembly
+// kernels at the integration points x_q = bar(q)^T X (basis.py:90-91) instead of being read
+// back from HBM as 8 Q bytes per element of pre-evaluated values.  The Python tracer
+// (basis/forms.py) records the arithmetic the callable applies to the coordinate columns of
+// `basis.integration_points`; include/tfem_assembly.h (tfem_source_program) is the format.
+//
+// Evaluation: a stack of four entries, each entry the values at the Q integration points of
+// one element (so the program is decoded once per element, not once per point).  The program
+// is read from the kernel-argument segment with wave-uniform scalar loads; every branch is
+// wave-uniform.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "tfem_assembly.h"
+
+namespace tfem {
+
+constexpr int kSrcMaxOps = TFEM_SOURCE_MAX_OPS;
+constexpr int kSrcStack = TFEM_SOURCE_STACK;
+
+// Device-side copy of a tfem_source_program in the real type of the launch.
+template <typename T>
+struct SrcProgram {
+  int n_ops;
+  int pad;
+  uint32_t opw[kSrcMaxOps / 4];  // four op codes per dword
+  T c[kSrcMaxOps];               // constant operand of op i (unused: 0)
+};
+
+// Host: validates (stack discipline, known ops) and converts.  Returns TFEM_OK or fails.
+template <typename T>
+int src_convert(const tfem_source_program *in, SrcProgram<T> *out);
+int src_validate(const tfem_source_program *in);
+
+#if defined(__HIPCC__)
+
+// sin / cos in fp64 for |x| < 2^30: k = rint(x / pi), r = x - k pi with pi in two doubles (both
+// steps fused multiply-adds: the reduction is exact to ~1e-33 k), the Taylor polynomial of
+// sin to r^21 on [-pi/2, pi/2] (truncation 1.3e-18), sign from the parity of k.  Within
+// 2.3e-16 absolute of the correctly rounded value up to |x| = 1e9 (measured against glibc on
+// 2e7 arguments); 19 instructions against ~60 on the short path of the library function.
+// Larger arguments take the library function (wave-uniform branch).
+__device__ __forceinline__ double src_sin_poly(double r) {
+  const double r2 = r * r;
+  double p = -1.0 / 51090942171709440000.0;
+  p = __builtin_fma(p, r2, 1.0 / 121645100408832000.0);
+  p = __builtin_fma(p, r2, -1.0 / 355687428096000.0);
+  p = __builtin_fma(p, r2, 1.0 / 1307674368000.0);
+  p = __builtin_fma(p, r2, -1.0 / 6227020800.0);
+  p = __builtin_fma(p, r2, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r2, -1.0 / 362880.0);
+  p = __builtin_fma(p, r2, 1.0 / 5040.0);
+  p = __builtin_fma(p, r2, -1.0 / 120.0);
+  p = __builtin_fma(p, r2, 1.0 / 6.0);
+  return __builtin_fma(-(r * r2), p, r);
+}
+
+constexpr double kSrcPiHi = 3.141592653589793116e+00, kSrcPiLo = 1.224646799147353207e-16;
+constexpr double kSrcInvPi = 0.318309886183790671537767526745;
+constexpr double kSrcTrigFastMax = 1.0e9;
+
+__device__ __forceinline__ double src_flip_sign(double s, int odd) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 b = __builtin_bit_cast(u32x2, s);
+  b.y ^= unsigned(odd) << 31;
+  return __builtin_bit_cast(double, b);
+}
+
+__device__ __forceinline__ double src_sin_fast(double x) {
+  const double k = __builtin_rint(x * kSrcInvPi);
+  double r = __builtin_fma(-k, kSrcPiHi, x);
+  r = __builtin_fma(-k, kSrcPiLo, r);
+  return src_flip_sign(src_sin_poly(r), int(k) & 1);
+}
+
+__device__ __forceinline__ double src_cos_fast(double x) {
+  // cos x = (-1)^(k+1) sin(x - (k + 1/2) pi), k = rint(x / pi - 1/2)
+  const double k = __builtin_rint(__builtin_fma(x, kSrcInvPi, -0.5));
+  const double kh = k + 0.5;
+  double r = __builtin_fma(-kh, kSrcPiHi, x);
+  r = __builtin_fma(-kh, kSrcPiLo, r);
+  return src_flip_sign(src_sin_poly(r), (int(k) & 1) ^ 1);
+}
+
+// A library function applied to every entry with ONE inlined copy of it: the loop is not
+// unrolled, each pass handles entry 0 and rotates the array by one (static register indices
+// only: a dynamic index would send the array to scratch memory).
+#define TFEM_SRC_ROTATE_APPLY(v, fn)                    \
+  _Pragma("unroll 1") for (int it = 0; it < QL; ++it) { \
+    const T t0 = fn(v[0]);                              \
+    _Pragma("unroll") for (int q = 0; q + 1 < QL; ++q) v[q] = v[q + 1]; \
+    v[QL - 1] = t0;                                     \
+  }
+
+template <typename T, int QL>
+__device__ __forceinline__ void src_sin(T (&v)[QL]) {
+  if constexpr (sizeof(T) == 8) {
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) big = big || !(__builtin_fabs(v[q]) < kSrcTrigFastMax);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) v[q] = src_sin_fast(v[q]);
+    } else {
+      TFEM_SRC_ROTATE_APPLY(v, sin)
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < QL; ++q) v[q] = sinf(v[q]);
+  }
+}
+
+template <typename T, int QL>
+__device__ __forceinline__ void src_cos(T (&v)[QL]) {
+  if constexpr (sizeof(T) == 8) {
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) big = big || !(__builtin_fabs(v[q]) < kSrcTrigFastMax);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) v[q] = src_cos_fast(v[q]);
+    } else {
+      TFEM_SRC_ROTATE_APPLY(v, cos)
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < QL; ++q) v[q] = cosf(v[q]);
+  }
+}
+
+template <typename T>
+using src_const_ptr = const SrcProgram<T> __attribute__((address_space(4))) *;
+
+// The program at byte `offset` of the kernel-argument segment (the launch structure is the
+// kernel's only parameter).
+template <typename T>
+__device__ __forceinline__ src_const_ptr<T> src_in_kernarg(size_t offset) {
+  typedef const char __attribute__((address_space(4))) *kbytes;
+  return (src_const_ptr<T>)((kbytes)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+
+// f at the QL points (x[q], y[q]) of one element -> out.  Wave-uniform control flow.
+template <typename T, int QL>
+__device__ __forceinline__ void src_run(src_const_ptr<T> p, const T (&x)[QL], const T (&y)[QL],
+                                        T (&out)[QL]) {
+  T s0[QL], s1[QL], s2[QL], s3[QL];
+#pragma unroll
+  for (int q = 0; q < QL; ++q) s0[q] = s1[q] = s2[q] = s3[q] = T(0);
+  const int n = p->n_ops;
+#define TFEM_SRC_PUSH(expr)            \
+  _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
+    s3[q] = s2[q];                     \
+    s2[q] = s1[q];                     \
+    s1[q] = s0[q];                     \
+    s0[q] = (expr);                    \
+  }
+#define TFEM_SRC_BINARY(expr)          \
+  _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
+    const T lo = s1[q], hi = s0[q];    \
+    s0[q] = (expr);                    \
+    s1[q] = s2[q];                     \
+    s2[q] = s3[q];                     \
+  }
+#define TFEM_SRC_UNARY(expr)           \
+  _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
+    const T t = s0[q];                 \
+    s0[q] = (expr);                    \
+  }
+#pragma unroll 1
+  for (int pc = 0; pc < n; ++pc) {
+    const uint32_t op = (p->opw[pc >> 2] >> (8 * (pc & 3))) & 0xFFu;
+    const T c = p->c[pc];
+    switch (op) {
+      case TFEM_SRC_PUSH_X: TFEM_SRC_PUSH(x[q]) break;
+      case TFEM_SRC_PUSH_Y: TFEM_SRC_PUSH(y[q]) break;
+      case TFEM_SRC_PUSH_C: TFEM_SRC_PUSH(c) break;
+      case TFEM_SRC_ADD: TFEM_SRC_BINARY(lo + hi) break;
+      case TFEM_SRC_SUB: TFEM_SRC_BINARY(lo - hi) break;
+      case TFEM_SRC_SUB_R: TFEM_SRC_BINARY(hi - lo) break;
+      case TFEM_SRC_MUL: TFEM_SRC_BINARY(lo * hi) break;
+      case TFEM_SRC_DIV: TFEM_SRC_BINARY(lo / hi) break;
+      case TFEM_SRC_DIV_R: TFEM_SRC_BINARY(hi / lo) break;
+      case TFEM_SRC_ADD_C: TFEM_SRC_UNARY(t + c) break;
+      case TFEM_SRC_MUL_C: TFEM_SRC_UNARY(t * c) break;
+      case TFEM_SRC_RSUB_C: TFEM_SRC_UNARY(c - t) break;
+      case TFEM_SRC_RDIV_C: TFEM_SRC_UNARY(c / t) break;
+      case TFEM_SRC_NEG: TFEM_SRC_UNARY(-t) break;
+      case TFEM_SRC_ABS:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(__builtin_fabs(t)) } else { TFEM_SRC_UNARY(__builtin_fabsf(t)) }
+        break;
+      case TFEM_SRC_POW_I: {  // t^n, n = 2 .. 8 by multiplications from the left (torch: x*x, x*x*x)
+        const int e = int(c);
+#pragma unroll
+        for (int q = 0; q < QL; ++q) {
+          const T t = s0[q];
+          T r = t * t;
+          for (int i = 2; i < e; ++i) r = r * t;
+          s0[q] = r;
+        }
+        break;
+      }
+      case TFEM_SRC_SIN: src_sin<T, QL>(s0); break;
+      case TFEM_SRC_COS: src_cos<T, QL>(s0); break;
+      case TFEM_SRC_EXP:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(exp(t)) } else { TFEM_SRC_UNARY(expf(t)) }
+        break;
+      case TFEM_SRC_SQRT:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(sqrt(t)) } else { TFEM_SRC_UNARY(sqrtf(t)) }
+        break;
+      case TFEM_SRC_LOG:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_ROTATE_APPLY(s0, log) } else { TFEM_SRC_ROTATE_APPLY(s0, logf) }
+        break;
+      case TFEM_SRC_TANH:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_ROTATE_APPLY(s0, tanh) } else { TFEM_SRC_ROTATE_APPLY(s0, tanhf) }
+        break;
+      default: break;
+    }
+  }
+#undef TFEM_SRC_PUSH
+#undef TFEM_SRC_BINARY
+#undef TFEM_SRC_UNARY
+#pragma unroll
+  for (int q = 0; q < QL; ++q) out[q] = s0[q];
+}
+
+#endif  // __HIPCC__
+
+}  // namespace tfem

@@ -29,17 +29,23 @@ def decode_rows(rows, slots):
     return {"id": ids, "flag": flag, "pos": pos, "k": k.astype(np.int64), "dpos": dpos.astype(np.int64)}
 
 
-def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=None, lamw=None):
+def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=None, lamw=None,
+                  conn=None, source=None, lam=None):
     """Returns (vals, writes, covered[, f]): CSR values of stiff_w-weighted stiffness + mass,
     how often every CSR entry was written, the number of rows covered and -- with source
-    values fq (E, Q) and the table lamw (3, Q) = l_i(q) w_q / 2 -- the load vector."""
+    values fq (E, Q) and the table lamw (3, Q) = l_i(q) w_q / 2 -- the load vector.
+    conn: the connectivity, to check the tiles' element vertex tables against.  source = (ops,
+    consts) with lam (3, Q) = l_i(q): the source values are not taken from fq but computed per
+    tile from the tile-local coordinates through tile_tverts, as the SRC kernels do."""
+    from oracle.assembly_oracle import source_program_eval
+
     slots, words = plan["slots"], plan["words"]
     desc = plan["desc"].reshape(-1, 20)
     rows = plan["rows"].reshape(-1, words)
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
-    fvec = np.full(coords.shape[0], np.nan) if fq is not None else None
+    fvec = np.full(coords.shape[0], np.nan) if (fq is not None or source is not None) else None
     ewords = (12 * slots + 31) // 32  # packed 12-bit slot codes
     row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
     for d in desc:
@@ -67,6 +73,19 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         else:
             tile_elems = plan["tile_elems"][elem_off:elem_off + n_elem]
         assert np.all(np.diff(tile_elems) > 0) and (n_elem <= 768 or not plan["elems_staged"])
+        tvert_off = int(d[19])
+        tv = plan["tile_tverts"][tvert_off:tvert_off + n_elem].astype(np.int64)
+        assert tv.shape[0] == n_elem
+        local = np.stack([tv & 0x3FF, (tv >> 10) & 0x3FF, (tv >> 20) & 0x3FF], axis=1)
+        assert n_elem == 0 or local.max() < n_vert
+        if conn is not None:  # the element's vertices, in the element's own local order
+            assert np.array_equal(gid[local], conn[tile_elems])
+        fq_tile = None
+        if source is not None:
+            cx, cy = xy[local][..., 0], xy[local][..., 1]  # (n_elem, 3)
+            xq = (np.outer(cx[:, 0], lam[0]) + np.outer(cx[:, 1], lam[1])) + np.outer(cx[:, 2], lam[2])
+            yq = (np.outer(cy[:, 0], lam[0]) + np.outer(cy[:, 1], lam[1])) + np.outer(cy[:, 2], lam[2])
+            fq_tile = source_program_eval(source[0], source[1], xq, yq)
         rowstart = plan["rowstart"][row_off:row_off + n_own]
         for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
             if b > a:  # what the consecutive-vertex kernel takes from the descriptor
@@ -103,7 +122,8 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
                 if fvec is not None:
                     elem, loc = int(tile_elems[se[i] & 0x3FF]), int(se[i] >> 10)
                     assert loc < 3
-                    facc += sdet * float(np.dot(fq[elem], lamw[loc]))
+                    values = fq_tile[se[i] & 0x3FF] if fq_tile is not None else fq[elem]
+                    facc += sdet * float(np.dot(values, lamw[loc]))
             targets = np.concatenate([rowstart[r] + pos[:k], [rowstart[r] + rec["dpos"][r]]])
             assert np.unique(targets).size == k + 1
             assert targets.max() < rowstart[r] + k + 1

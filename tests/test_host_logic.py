@@ -16,6 +16,13 @@ from ring_emulator import run_ring_plan
 from p2rows_emulator import run_p2_plan
 
 
+#: 2 pi^2 sin(pi x) sin(pi y) as the tracer compiles it (tests/test_assembly.py:75-77)
+_SIN_SIN_PROGRAM = (
+    [orc.SRC_PUSH_X, orc.SRC_MUL_C, orc.SRC_SIN, orc.SRC_MUL_C, orc.SRC_PUSH_Y, orc.SRC_MUL_C, orc.SRC_SIN, orc.SRC_MUL],
+    [0.0, np.pi, 0.0, 2.0 * np.pi**2, 0.0, np.pi, 0.0, 0.0],
+)
+
+
 @pytest.fixture(autouse=True)
 def _cpu_defaults():
     torch.set_default_device("cpu")
@@ -34,7 +41,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in tfem_assembly.h but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.tfem_abi_version() == 1
+    assert lib.tfem_abi_version() == _native.ABI_VERSION
+    version = int(re.search(r"#define TFEM_ABI_VERSION (\d+)", header).group(1))
+    assert version == _native.ABI_VERSION
     assert lib.tfem_device_count() >= 0
     assert [lib.tfem_quadrature_size(q) for q in (1, 2, 3, 4, 5)] == [1, 3, 4, 6, 0]
 
@@ -220,6 +229,11 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
     # the load vector through the plan's row_elems (element and local index per slot)
     want_f = orc.assemble_linear(fl, mesh["triangles"], nv).reshape(-1)
     assert scaled_error(fvec, want_f) <= 1e-13
+    # the same vector with the source evaluated per tile from the tile's own coordinates through
+    # the element vertex table (what the SRC kernels do), program of tests/test_assembly.py:75-77
+    _, _, _, fsrc = run_ring_plan(plan, mesh["vertices"], colind.shape[0], w, md, mo, lamw=lamw,
+                                  conn=mesh["triangles"], source=_SIN_SIN_PROGRAM, lam=bary.T)
+    assert scaled_error(fsrc, want_f) <= 1e-13
 
 
 def test_ring_plan_open_fans_and_isolated_vertices():
@@ -322,6 +336,9 @@ def test_random_meshes_through_the_plan_emulators(seed):
         assert scaled_error(vals, want) <= 1e-12
         fl = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
         assert scaled_error(fvec, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
+        _, _, _, fsrc = run_ring_plan(plan, verts, colind.shape[0], 0.5 * weights.sum(), lamw=lamw,
+                                      conn=tris, source=_SIN_SIN_PROGRAM, lam=bary.T)
+        assert scaled_error(fsrc, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
     try:
         tplan = tile_plan_host(tris, nv, verts, rowptr, colind)
     except NotImplementedError:
@@ -351,7 +368,15 @@ def test_tile_plan_rejects_rows_longer_than_16_entries():
 class _FakeBasis:
     def __init__(self):
         self.integration_points = torch.rand(5, 4, 1, 2)
+        self.v = torch.rand(4, 3, 1)
+        self.v_grad = torch.rand(5, 1, 3, 2)
         self.mesh = "mesh"
+
+
+def _rhs(x, y):
+    import math
+
+    return 2.0 * math.pi**2 * torch.sin(math.pi * x) * torch.sin(math.pi * y)
 
 
 def test_tracer_recognises_the_reference_vocabulary():
@@ -364,33 +389,144 @@ def test_tracer_recognises_the_reference_vocabulary():
     assert (e.alpha, e.beta) == (1.0, 1.0)
     e = forms.trace(lambda basis: 2.5 * (basis.v @ basis.v.mT) + (basis.v_grad @ basis.v_grad.mT) * 3, b, (), {})
     assert (e.alpha, e.beta) == (3.0, 2.5)
+    e = forms.trace(lambda basis: basis.v_grad @ basis.v_grad.mT - basis.v @ basis.v.mT, b, (), {})
+    assert (e.alpha, e.beta) == (1.0, -1.0)
 
-    def load(basis, scale):
+    def load(basis, scale):  # tests/test_assembly.py:75-84
         x, y = torch.split(basis.integration_points, 1, dim=-1)
-        return scale * torch.sin(x) * y * basis.v
+        return scale * _rhs(x, y) * basis.v
 
-    e = forms.trace(load, b, (2.0,), {})
-    assert isinstance(e, forms.LinearExpr) and e.coefficient.shape == (5, 4, 1, 1)
+    e = forms.trace(load, b, (1.0,), {})
+    assert isinstance(e, forms.LinearExpr) and isinstance(e.coefficient, forms.SourceExpr) and e.flux is None
+    names = [name for name, _ in forms.compile_ops(e.coefficient.node)]
+    assert names == ["PUSH_X", "MUL_C", "SIN", "MUL_C", "PUSH_Y", "MUL_C", "SIN", "MUL", "MUL_C"]
+    assert torch.equal(e.materialize(), load(b, 1.0))  # the same torch operations in the same order
+    program = e.coefficient.program()
+    assert program.n_ops == 9 and list(program.ops[:3]) == [forms.OPS["PUSH_X"], forms.OPS["MUL_C"], forms.OPS["SIN"]]
+    # coordinate columns by indexing; a tensor coefficient (evaluated by the caller)
     e = forms.trace(lambda basis: basis.v * basis.integration_points[..., [0]], b, (), {})
-    assert isinstance(e, forms.LinearExpr)
-    assert forms.trace(lambda basis: basis.mesh, b, (), {}) is None  # real attributes pass through
+    assert isinstance(e, forms.LinearExpr) and e.coefficient.node == ("x",)
+    e = forms.trace(lambda basis: basis.integration_points[..., 1:2] ** 2 * basis.v, b, (), {})
+    assert e.coefficient.node == ("powi", ("y",), 2)
+    coefficient = torch.rand(5, 4, 1, 1)
+    e = forms.trace(lambda basis: coefficient * basis.v, b, (), {})
+    assert isinstance(e, forms.LinearExpr) and e.coefficient is coefficient
+    # the fracture example's source (example_fractures_fem.py:69-99) on a 2-D mesh
+    def frac(basis):
+        x, y = torch.split(basis.integration_points, 1, dim=-1)
+        return (6.0 * (y - y**2) * torch.abs(x) - 2.0 * (torch.abs(x) ** 3 - torch.abs(x))) * basis.v
+
+    e = forms.trace(frac, b, (), {})
+    assert isinstance(e.coefficient, forms.SourceExpr) and e.coefficient.program() is not None
+    assert torch.equal(e.materialize(), frac(b))
+    # a functional of the coordinates (tests/test_assembly.py:86-90)
+    e = forms.trace(lambda basis: _rhs(*torch.split(basis.integration_points, 1, dim=-1)) ** 2, b, (), {})
+    assert isinstance(e, forms.SourceExpr) and forms.compile_ops(e.node)[-1] == ("POW_I", 2.0)
+    assert forms.trace(lambda basis: basis.mesh, b, (), {}) == "mesh"  # real attributes pass through
 
 
-def test_tracer_falls_back_on_anything_else():
+def test_tracer_residual_form_with_an_opaque_gradient_field():
+    """examples/example_weak.py:64-75: f v - v_grad @ g.mT with g from code the tracer cannot see
+    into (requires_grad_ + autograd.grad on the points, model/neural_network.py:85-100)."""
+    from pytorch_fem_solver_amd.basis import forms
+
+    b = _FakeBasis()
+    lin = torch.nn.Linear(2, 1).double()
+
+    def gradient(points):
+        points.requires_grad_(True)
+        out = torch.tanh(lin(points))
+        return torch.autograd.grad([out], [points], [torch.ones_like(out)], create_graph=True)[0]
+
+    def residual(basis, grad):
+        points = basis.integration_points
+        x, y = torch.split(points, 1, dim=-1)
+        return _rhs(x, y) * basis.v - (basis.v_grad @ grad(points).mT)
+
+    e = forms.trace(residual, b, (gradient,), {})
+    assert isinstance(e, forms.LinearExpr) and isinstance(e.coefficient, forms.SourceExpr)
+    assert e.flux.shape == (5, 4, 1, 2) and e.flux_sign == -1.0 and e.flux.requires_grad
+    assert not b.integration_points.requires_grad  # the basis's cached tensor is left alone
+    want = residual(_FakeBasis.__new__(_FakeBasis).__class__() if False else b, gradient)
+    assert torch.allclose(e.materialize(), want, rtol=0, atol=1e-15)
+    # the loss differentiates through the flux into the network
+    e.materialize().sum().backward()
+    assert lin.weight.grad is not None and float(lin.weight.grad.abs().sum()) > 0
+
+
+def test_tracer_hands_back_tensors_for_anything_else():
+    """Outside the vocabulary the symbols turn into the tensors they stand for: the callable runs
+    once and the result equals the callable on the real basis."""
     from pytorch_fem_solver_amd.basis import forms
 
     b = _FakeBasis()
     unknown = [
         lambda basis: basis.v @ basis.v_grad[..., [0]].mT,           # convection: indexing
-        lambda basis: basis.v_grad @ basis.v.mT,                     # mixed
+        lambda basis: basis.v_grad[..., [1]] @ basis.v.mT,           # mixed
         lambda basis: torch.sin(basis.v),                            # torch function on a symbol
-        lambda basis: basis.v_grad @ basis.v_grad.mT - basis.v @ basis.v.mT,
         lambda basis: basis.v * basis.v,
         lambda basis: (basis.v_grad @ basis.v_grad.mT) * torch.ones(5, 4, 1, 1),  # tensor coefficient
         lambda basis: basis.integration_points * 2.0,               # no symbol at all
+        lambda basis: torch.cat(torch.split(basis.integration_points, 1, dim=-1), dim=-1).sum(-1, keepdim=True) * basis.v,
+        lambda basis: torch.split(basis.integration_points, 1, dim=-1)[0] ** 2.5,  # pow outside the format
     ]
     for fn in unknown:
-        assert forms.trace(fn, b, (), {}) is None
+        got = forms.trace(fn, b, (), {})
+        got = forms.materialize(got)
+        assert isinstance(got, torch.Tensor) and not isinstance(got, forms.PointsSymbol)
+        assert torch.equal(got, fn(b))
+    calls = []
+
+    def assigns(basis):  # the proxy refuses; the real basis is used, and directly from then on
+        calls.append(type(basis).__name__)
+        basis.scratch = 1
+        return basis.v * 2.0
+
+    assert torch.equal(forms.trace(assigns, b, (), {}), b.v * 2.0)
+    assert torch.equal(forms.trace(assigns, b, (), {}), b.v * 2.0)
+    assert calls == ["TracingBasis", "_FakeBasis", "_FakeBasis"]
+
+
+def test_source_program_compiler_and_validator():
+    """Sethi-Ullman ordering keeps the stack within the format; the library's validator accepts
+    what the compiler emits and rejects broken programs."""
+    import ctypes as ct
+
+    from pytorch_fem_solver_amd import _native
+    from pytorch_fem_solver_amd.basis import forms
+    from oracle import assembly_oracle as orc
+
+    lib = _native.load()
+    b = _FakeBasis()
+    x, y = forms.SourceExpr(b, ("x",)), forms.SourceExpr(b, ("y",))
+    deep = x + (y * (x - (y / ((x + 2.0) * (y - x)))))  # right-leaning: needs the reversed operations
+    ops = forms.compile_ops(deep.node)
+    assert ops is not None and {"SUB_R", "DIV_R"} <= {name for name, _ in ops}
+    program = deep.program()
+    assert lib.tfem_source_validate(ct.byref(program)) == 0
+    pts = b.integration_points
+    got = orc.source_program_eval(list(program.ops[: program.n_ops]), list(program.consts[: program.n_ops]),
+                                  pts[..., 0:1].numpy(), pts[..., 1:2].numpy())
+    assert np.allclose(got, deep.materialize().numpy(), rtol=1e-15, atol=0)
+    balanced = ((x + y) * (x - y)) / ((x * y) + (x / y))  # needs 3 entries
+    assert forms.compile_ops(balanced.node) is not None
+    too_deep = balanced
+    for _ in range(3):
+        too_deep = (too_deep * (x + 1.0)) / ((too_deep - y) * (too_deep + y))
+    assert too_deep.program() is None  # more than 32 operations / 4 entries: torch evaluates it
+    bad = _native.SourceProgram()
+    bad.n_ops = 1
+    bad.ops[0] = forms.OPS["ADD"]
+    assert lib.tfem_source_validate(ct.byref(bad)) == 1 and b"empty stack" in lib.tfem_last_error()
+    bad.ops[0] = forms.OPS["PUSH_X"]
+    bad.n_ops = 2
+    bad.ops[1] = forms.OPS["PUSH_Y"]
+    assert lib.tfem_source_validate(ct.byref(bad)) == 1 and b"leaves 2" in lib.tfem_last_error()
+    bad.ops[1] = forms.OPS["POW_I"]
+    bad.consts[1] = 2.5
+    assert lib.tfem_source_validate(ct.byref(bad)) == 1
+    bad.ops[1] = 99
+    assert lib.tfem_source_validate(ct.byref(bad)) == 1
 
 
 # ---------------------------------------------------------------------------------------
