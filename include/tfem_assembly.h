@@ -311,10 +311,11 @@ int tfem_p1_assemble_rings(const void *coords, int real_bytes, int64_t n_verts, 
  * those expressions once and the assembly launch re-evaluates them, so the 8 Q bytes
  * per element of pre-evaluated source values never exist in HBM.
  *   A stack machine of TFEM_SOURCE_STACK entries.  ops[i] with constant consts[i]:
- *   PUSH_X / PUSH_Y / PUSH_C   push x, y, or the constant
+ *   PUSH_X / PUSH_Y / PUSH_C   push c * x, c * y, or the constant c
  *   ADD SUB MUL DIV            pop hi, pop lo, push lo (op) hi;  SUB_R, DIV_R: hi (op) lo
  *   ADD_C MUL_C RSUB_C RDIV_C  top = top + c, top * c, c - top, c / top
- *   NEG ABS SIN COS EXP SQRT LOG TANH   top = fn(top)
+ *   NEG ABS                    top = -top, |top|
+ *   SIN COS EXP SQRT LOG TANH  top = c * fn(top)
  *   POW_I                      top = top^n, n = (int)c in 2..8, by multiplications
  *                              from the left (x*x, x*x*x as torch evaluates them)
  * A valid program never pops an empty stack, never exceeds the stack and leaves

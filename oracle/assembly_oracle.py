@@ -265,9 +265,9 @@ def source_program_eval(ops, consts, x, y):
     for op, c in zip(ops, consts):
         c = x.dtype.type(c)
         if op == SRC_PUSH_X:
-            stack.append(x)
+            stack.append(c * x)
         elif op == SRC_PUSH_Y:
-            stack.append(y)
+            stack.append(c * y)
         elif op == SRC_PUSH_C:
             stack.append(np.full_like(x, c))
         elif op in (SRC_ADD, SRC_SUB, SRC_SUB_R, SRC_MUL, SRC_DIV, SRC_DIV_R):
@@ -289,8 +289,10 @@ def source_program_eval(ops, consts, x, y):
             for _ in range(2, int(c)):
                 r = r * t
             stack.append(r)
-        elif op in unary:
+        elif op in (SRC_NEG, SRC_ABS):
             stack.append(unary[op](stack.pop()))
+        elif op in unary:  # the functions carry a factor
+            stack.append(c * unary[op](stack.pop()))
         else:
             raise ValueError(f"unknown source operation {op}")
     if len(stack) != 1:

@@ -485,17 +485,30 @@ def _need(node):
     return max(na, nb) if na != nb else na + 1
 
 
+_SCALED = ("PUSH_X", "PUSH_Y", "SIN", "COS", "EXP", "SQRT", "LOG", "TANH")  # ops with a factor
+
+
+def _emit_scale(ops, factor):
+    """top *= factor: folded into the operation that produced the top when that operation has
+    a factor of its own that is still 1 (c * x, c * sin(.): the same product), else MUL_C."""
+    if ops and ops[-1][0] in _SCALED and ops[-1][1] == 1.0:
+        ops[-1] = (ops[-1][0], factor)
+    else:
+        ops.append(("MUL_C", factor))
+
+
 def _emit(node, ops):
     kind = node[0]
     if kind == "x":
-        ops.append(("PUSH_X", 0.0))
+        ops.append(("PUSH_X", 1.0))
     elif kind == "y":
-        ops.append(("PUSH_Y", 0.0))
+        ops.append(("PUSH_Y", 1.0))
     elif kind == "c":
         ops.append(("PUSH_C", node[1]))
     elif kind in _UNARY:
         _emit(node[1], ops)
-        ops.append((_UNARY_OPS[kind], 0.0))
+        name = _UNARY_OPS[kind]
+        ops.append((name, 1.0 if name in _SCALED else 0.0))
     elif kind == "powi":
         _emit(node[1], ops)
         ops.append(("POW_I", float(node[2])))
@@ -508,13 +521,16 @@ def _emit(node, ops):
             elif kind == "sub":
                 ops.append(("ADD_C", -b[1]))
             elif kind == "mul":
-                ops.append(("MUL_C", b[1]))
+                _emit_scale(ops, b[1])
             else:  # expr / c: a true division, as torch evaluates it
                 ops.append(("PUSH_C", b[1]))
                 ops.append(("DIV", 0.0))
         elif a[0] == "c":  # constant (op) expr
             _emit(b, ops)
-            ops.append(({"add": "ADD_C", "sub": "RSUB_C", "mul": "MUL_C", "div": "RDIV_C"}[kind], a[1]))
+            if kind == "mul":
+                _emit_scale(ops, a[1])
+            else:
+                ops.append(({"add": "ADD_C", "sub": "RSUB_C", "div": "RDIV_C"}[kind], a[1]))
         elif _need(a) >= _need(b):
             _emit(a, ops)
             _emit(b, ops)

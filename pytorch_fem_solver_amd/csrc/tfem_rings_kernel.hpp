@@ -399,7 +399,7 @@ template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool K
 // The matrix-only 15-slot instantiations are asked for 3 waves per SIMD: left alone, hipcc's
 // scheduler hoists every LDS read of the unrolled fan loop and ends at 250 VGPRs (2 waves); with
 // the bound it needs 112-128 and nothing spills (the load-vector instantiations would spill).
-__global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_p1_rings(const RingArgs<T> a) {
+__global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (SLOTS > 7 && QL == 0) ? 3 : 1) void k_p1_rings(const RingArgs<T> a) {
   constexpr bool LOAD = QL > 0;
   constexpr bool FQ = LOAD && !SRC;  // source values streamed from memory
   static_assert(KMAT || LOAD, "nothing to assemble");
@@ -433,11 +433,19 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   const ring_rsrc_t r_fout = ring_rsrc(a.fout, a.fout_bytes);
   constexpr unsigned kRecBytes = unsigned(4 * RingRec<SLOTS>::kWords);
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
-  if (LOAD && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
+  if (FQ && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
     gtab[3 * a.lds_elem + tid] = T(0);
+  // SRC: the same LDS region holds the load-vector accumulators, one per tile-local vertex,
+  // double-buffered by tile parity (zeroed here; the other buffer again in every phase D)
+  T *faccbuf = gtab;
+  if (SRC)
+    for (int i = tid; i < 2 * a.lds_vert; i += kRingBlock) faccbuf[i] = T(0);
 
+  // SRC: the program, one operation per lane, for the whole launch
+  SrcLanes<T> prog;
+  if constexpr (SRC) prog = src_load_lanes<T>(src_in_kernarg<T>(__builtin_offsetof(RingArgs<T>, src)));
   RingRec<SLOTS> rec, rec_ld;
-  uint32_t se[LOAD ? kEW : 1], se_ld[LOAD ? kEW : 1];  // slot codes of the row (load vector)
+  uint32_t se[FQ ? kEW : 1], se_ld[FQ ? kEW : 1];  // slot codes of the row (load vector from fq)
   unsigned eid[FQ ? kRingElemPerLane : 1], eid_ld[FQ ? kRingElemPerLane : 1];  // element ids, like gid_*
   T fqe_ld[FQ ? kRingElemPerLane : 1][QL > 0 ? QL : 1];  // their source values
   unsigned tev[SRC ? kRingElemPerLane : 1], tev_ld[SRC ? kRingElemPerLane : 1];  // local vertex triples
@@ -529,11 +537,11 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
           r_plan, a.off_tverts + (l < d.n_elem ? unsigned(d.tvert_off + l) : kNone) * 4u, 0, kStreamLoadNT);
     }
   };
-  // SRC: g[T][i] = sum_q f(x_q) l_i(q) w_q / 2 of the tile's elements from the tile's
-  // coordinates in LDS (basis.py:90-91: x_q = bar(q)^T X) -> LDS
+  // SRC: det_T g[T][i], g[T][i] = sum_q f(x_q) l_i(q) w_q / 2, of the tile's elements from the
+  // tile's coordinates in LDS (basis.py:90-91: x_q = bar(q)^T X), added to the accumulators of
+  // the elements' vertices in LDS (element form: no slot codes, nothing per fan slot)
   auto compute_g = [&](const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1], const T *xyc, T *dst) {
     if constexpr (SRC) {
-      const src_const_ptr<T> prog = src_in_kernarg<T>(__builtin_offsetof(RingArgs<T>, src));
       // the loop is not unrolled (one copy of the interpreter): every pass takes entry 0 and
       // rotates the array -- a register array indexed by the loop counter would go to scratch
       unsigned codes[kRingElemPerLane];
@@ -558,17 +566,22 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
         }
         src_run<T, (QL > 0 ? QL : 1)>(prog, xq, yq, fv);
         if (l < d.n_elem) {
+          // signed determinant in the element's own vertex order (element_tri.py:139); the
+          // element's three shares go to the accumulators of its vertices (ds_add_f64; the
+          // halo vertices' sums are never read)
+          const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             T g = T(0);
 #pragma unroll
             for (int q = 0; q < QL; ++q) g = g + fv[q] * a.lamw[i][q];
-            dst[3 * l + i] = g;
+            atomicAdd(dst + ((code >> (10 * i)) & 0x3FFu), det * g);
           }
         }
       }
     }
   };
+
   auto load_tile = [&](const RingDesc &d, unsigned g_own, unsigned g_halo) {
     const int r = d.row0 + lane;
     const unsigned row = r < d.row1 ? unsigned(d.row_off + r) : kNone;
@@ -576,14 +589,14 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       ring_load_rec<SLOTS>(r_plan, a.off_rows + row * kRecBytes, rec_ld);
       if (!CHUNK)
         rowstart_ld = int(__builtin_amdgcn_raw_buffer_load_b32(r_plan, a.off_rowstart + row * 4u, 0, 0));
-      if (LOAD) {  // 12-bit slot codes: 3 (SLOTS 7) or 6 dwords per row
+      if (FQ) {  // 12-bit slot codes: 3 (SLOTS 7) or 6 dwords per row
         const unsigned eb = a.off_elems + row * unsigned(4 * kEW);
 #pragma unroll
         for (int i = 0; i < kEW; i += 3) {
           const ru32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r_plan, eb + unsigned(4 * i), 0, kStreamLoadNT);
-          se_ld[LOAD ? i : 0] = v.x;
-          se_ld[LOAD ? i + 1 : 0] = v.y;
-          se_ld[LOAD ? i + 2 : 0] = v.z;
+          se_ld[FQ ? i : 0] = v.x;
+          se_ld[FQ ? i + 1 : 0] = v.y;
+          se_ld[FQ ? i + 2 : 0] = v.z;
         }
       }
     }
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
   rowstart = rowstart_ld;
   gid_row = gid_own;
 #pragma unroll
-  for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
+  for (int i = 0; i < (FQ ? kEW : 1); ++i) se[i] = se_ld[i];
 #pragma unroll
   for (int j = 0; j < (FQ ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
 #pragma unroll
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
     if (SRC) {
       // ---- G ---- source values of tile k (its coordinates are complete).  Before A: the
       // registers of tile k+1's loads are not live while the program runs (3 workgroups per CU)
-      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, gtab);
+      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * a.lds_vert);
       ring_lds_barrier();
     }
     // ---- A ----
@@ -670,9 +683,9 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       const int my_row = dc.row0 + lane;
       const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
       if (banded)
-        ring_row<T, SLOTS, MASS, LOAD, kBandSlots>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
+        ring_row<T, SLOTS, MASS, FQ, kBandSlots>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
       else
-        ring_row<T, SLOTS, MASS, LOAD>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
+        ring_row<T, SLOTS, MASS, FQ>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
     } else {
       diag = T(1);
 #pragma unroll
@@ -687,7 +700,11 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
       total = banded ? ring_stage<T, SLOTS, kBandSlots>(rec, off, diag, my_stage, pre)
                      : ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
     T facc = T(0);
-    if (LOAD) {
+    if (SRC) {  // the row's sum is complete: one LDS read
+      const int my_row = dc.row0 + lane;
+      facc = faccbuf[cur * a.lds_vert + (my_row < dc.row1 ? my_row : 0)];
+    }
+    if (FQ) {
       const T *g = gtab;
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
@@ -711,6 +728,11 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
                                          // insertion knows the loads have landed
     if (timing) t4 = ring_stamp();
     // ---- D ----
+    if (SRC) {
+      // the accumulators the NEXT tile adds to (the other buffer): the rows of the previous tile
+      // read them before the last barrier E, the next tile's G starts behind the coming one
+      for (int i = tid; i < a.lds_vert; i += kRingBlock) faccbuf[(cur ^ 1) * a.lds_vert + i] = T(0);
+    }
     if (t_n >= 0) {
       park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
       if (FQ) {
@@ -752,7 +774,7 @@ __global__ __launch_bounds__(kRingBlock, (SLOTS > 7 && QL == 0) ? 3 : 1) void k_
     rowstart = rowstart_ld;
     gid_row = gid_own;
 #pragma unroll
-    for (int i = 0; i < (LOAD ? kEW : 1); ++i) se[i] = se_ld[i];
+    for (int i = 0; i < (FQ ? kEW : 1); ++i) se[i] = se_ld[i];
 #pragma unroll
     for (int j = 0; j < (FQ ? kRingElemPerLane : 1); ++j) eid[j] = eid_ld[j];
 #pragma unroll

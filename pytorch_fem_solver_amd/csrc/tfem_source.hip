@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kSrcBlock) void k_source_eval(const SrcEvalArgs<T, 
     yq[q] = (a.lam[0][q] * y0 + a.lam[1][q] * y1) + a.lam[2][q] * y2;
   }
   using Args = SrcEvalArgs<T, I>;
-  src_run<T, Q>(src_in_kernarg<T>(__builtin_offsetof(Args, src)), xq, yq, fv);
+  const SrcLanes<T> prog = src_load_lanes<T>(src_in_kernarg<T>(__builtin_offsetof(Args, src)));
+  src_run<T, Q>(prog, xq, yq, fv);
   if (e < a.n_elems) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) a.fq[Q * e + q] = fv[q];

@@ -7,7 +7,7 @@
 //
 // Evaluation: a stack of four entries, each entry the values at the Q integration points of
 // one element (so the program is decoded once per element, not once per point).  The program
-// is read from the kernel-argument segment with wave-uniform scalar loads; every branch is
+// sits in registers, one operation per lane, and is fetched with v_readlane; every branch is
 // wave-uniform.
 #pragma once
 
@@ -144,54 +144,96 @@ __device__ __forceinline__ src_const_ptr<T> src_in_kernarg(size_t offset) {
   return (src_const_ptr<T>)((kbytes)__builtin_amdgcn_kernarg_segment_ptr() + offset);
 }
 
+// The program as every wave keeps it while the kernel runs: lane i holds operation i and its
+// constant (3 VGPRs).  The interpreter fetches operation pc with v_readlane -- a few cycles --
+// instead of scalar loads from the kernel-argument segment, whose latency (two dependent loads
+// per operation) nothing would hide.
+template <typename T>
+struct SrcLanes {
+  uint32_t op;
+  T c;
+  int n_ops;  // wave-uniform
+};
+
+template <typename T>
+__device__ __forceinline__ SrcLanes<T> src_load_lanes(src_const_ptr<T> p) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & (kSrcMaxOps - 1);
+  SrcLanes<T> r;
+  r.op = (p->opw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+  r.c = p->c[i];
+  r.n_ops = p->n_ops;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T src_lane_const(const SrcLanes<T> &prog, int pc) {
+  if constexpr (sizeof(T) == 8) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 b = __builtin_bit_cast(u32x2, prog.c);
+    return __builtin_bit_cast(double, u32x2{unsigned(__builtin_amdgcn_readlane(int(b.x), pc)),
+                                            unsigned(__builtin_amdgcn_readlane(int(b.y), pc))});
+  } else {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prog.c), pc));
+  }
+}
+
 // f at the QL points (x[q], y[q]) of one element -> out.  Wave-uniform control flow.
 template <typename T, int QL>
-__device__ __forceinline__ void src_run(src_const_ptr<T> p, const T (&x)[QL], const T (&y)[QL],
+__device__ __forceinline__ void src_run(const SrcLanes<T> &prog, const T (&x)[QL], const T (&y)[QL],
                                         T (&out)[QL]) {
-  T s0[QL], s1[QL], s2[QL], s3[QL];
+  T s0[QL], s1[QL], s2[QL], s3[QL], lo[QL];
 #pragma unroll
-  for (int q = 0; q < QL; ++q) s0[q] = s1[q] = s2[q] = s3[q] = T(0);
-  const int n = p->n_ops;
-#define TFEM_SRC_PUSH(expr)            \
-  _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
-    s3[q] = s2[q];                     \
-    s2[q] = s1[q];                     \
-    s1[q] = s0[q];                     \
-    s0[q] = (expr);                    \
-  }
-#define TFEM_SRC_BINARY(expr)          \
-  _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
-    const T lo = s1[q], hi = s0[q];    \
-    s0[q] = (expr);                    \
-    s1[q] = s2[q];                     \
-    s2[q] = s3[q];                     \
-  }
-#define TFEM_SRC_UNARY(expr)           \
+  for (int q = 0; q < QL; ++q) s0[q] = s1[q] = s2[q] = s3[q] = lo[q] = T(0);
+  const int n = prog.n_ops;
+  // Every operation leaves its result in s0; the stack moves (push: everything one down; binary:
+  // the second operand out into `lo`, everything one up) happen in two places in front of the
+  // switch, so that the switch's cases only differ in s0 -- with the moves inside the cases
+  // hipcc copies all four entries between register sets where the cases join.
+#define TFEM_SRC_SET(expr)             \
   _Pragma("unroll") for (int q = 0; q < QL; ++q) { \
     const T t = s0[q];                 \
+    const T l = lo[q];                 \
+    (void)t;                           \
+    (void)l;                           \
     s0[q] = (expr);                    \
   }
 #pragma unroll 1
   for (int pc = 0; pc < n; ++pc) {
-    const uint32_t op = (p->opw[pc >> 2] >> (8 * (pc & 3))) & 0xFFu;
-    const T c = p->c[pc];
+    const uint32_t op = uint32_t(__builtin_amdgcn_readlane(int(prog.op), pc));
+    const T c = src_lane_const<T>(prog, pc);
+    if (op <= TFEM_SRC_PUSH_C) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) {
+        s3[q] = s2[q];
+        s2[q] = s1[q];
+        s1[q] = s0[q];
+      }
+    } else if (op <= TFEM_SRC_DIV_R) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) {
+        lo[q] = s1[q];
+        s1[q] = s2[q];
+        s2[q] = s3[q];
+      }
+    }
     switch (op) {
-      case TFEM_SRC_PUSH_X: TFEM_SRC_PUSH(x[q]) break;
-      case TFEM_SRC_PUSH_Y: TFEM_SRC_PUSH(y[q]) break;
-      case TFEM_SRC_PUSH_C: TFEM_SRC_PUSH(c) break;
-      case TFEM_SRC_ADD: TFEM_SRC_BINARY(lo + hi) break;
-      case TFEM_SRC_SUB: TFEM_SRC_BINARY(lo - hi) break;
-      case TFEM_SRC_SUB_R: TFEM_SRC_BINARY(hi - lo) break;
-      case TFEM_SRC_MUL: TFEM_SRC_BINARY(lo * hi) break;
-      case TFEM_SRC_DIV: TFEM_SRC_BINARY(lo / hi) break;
-      case TFEM_SRC_DIV_R: TFEM_SRC_BINARY(hi / lo) break;
-      case TFEM_SRC_ADD_C: TFEM_SRC_UNARY(t + c) break;
-      case TFEM_SRC_MUL_C: TFEM_SRC_UNARY(t * c) break;
-      case TFEM_SRC_RSUB_C: TFEM_SRC_UNARY(c - t) break;
-      case TFEM_SRC_RDIV_C: TFEM_SRC_UNARY(c / t) break;
-      case TFEM_SRC_NEG: TFEM_SRC_UNARY(-t) break;
+      case TFEM_SRC_PUSH_X: TFEM_SRC_SET(c * x[q]) break;
+      case TFEM_SRC_PUSH_Y: TFEM_SRC_SET(c * y[q]) break;
+      case TFEM_SRC_PUSH_C: TFEM_SRC_SET(c) break;
+      case TFEM_SRC_ADD: TFEM_SRC_SET(l + t) break;
+      case TFEM_SRC_SUB: TFEM_SRC_SET(l - t) break;
+      case TFEM_SRC_SUB_R: TFEM_SRC_SET(t - l) break;
+      case TFEM_SRC_MUL: TFEM_SRC_SET(l * t) break;
+      case TFEM_SRC_DIV: TFEM_SRC_SET(l / t) break;
+      case TFEM_SRC_DIV_R: TFEM_SRC_SET(t / l) break;
+      case TFEM_SRC_ADD_C: TFEM_SRC_SET(t + c) break;
+      case TFEM_SRC_MUL_C: TFEM_SRC_SET(t * c) break;
+      case TFEM_SRC_RSUB_C: TFEM_SRC_SET(c - t) break;
+      case TFEM_SRC_RDIV_C: TFEM_SRC_SET(c / t) break;
+      case TFEM_SRC_NEG: TFEM_SRC_SET(-t) break;
       case TFEM_SRC_ABS:
-        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(__builtin_fabs(t)) } else { TFEM_SRC_UNARY(__builtin_fabsf(t)) }
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(__builtin_fabs(t)) } else { TFEM_SRC_SET(__builtin_fabsf(t)) }
         break;
       case TFEM_SRC_POW_I: {  // t^n, n = 2 .. 8 by multiplications from the left (torch: x*x, x*x*x)
         const int e = int(c);
@@ -204,26 +246,27 @@ __device__ __forceinline__ void src_run(src_const_ptr<T> p, const T (&x)[QL], co
         }
         break;
       }
-      case TFEM_SRC_SIN: src_sin<T, QL>(s0); break;
-      case TFEM_SRC_COS: src_cos<T, QL>(s0); break;
+      // the functions: top = c * fn(top)
+      case TFEM_SRC_SIN: src_sin<T, QL>(s0); TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_COS: src_cos<T, QL>(s0); TFEM_SRC_SET(c * t) break;
       case TFEM_SRC_EXP:
-        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(exp(t)) } else { TFEM_SRC_UNARY(expf(t)) }
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(c * exp(t)) } else { TFEM_SRC_SET(c * expf(t)) }
         break;
       case TFEM_SRC_SQRT:
-        if constexpr (sizeof(T) == 8) { TFEM_SRC_UNARY(sqrt(t)) } else { TFEM_SRC_UNARY(sqrtf(t)) }
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(c * sqrt(t)) } else { TFEM_SRC_SET(c * sqrtf(t)) }
         break;
       case TFEM_SRC_LOG:
         if constexpr (sizeof(T) == 8) { TFEM_SRC_ROTATE_APPLY(s0, log) } else { TFEM_SRC_ROTATE_APPLY(s0, logf) }
+        TFEM_SRC_SET(c * t)
         break;
       case TFEM_SRC_TANH:
         if constexpr (sizeof(T) == 8) { TFEM_SRC_ROTATE_APPLY(s0, tanh) } else { TFEM_SRC_ROTATE_APPLY(s0, tanhf) }
+        TFEM_SRC_SET(c * t)
         break;
       default: break;
     }
   }
-#undef TFEM_SRC_PUSH
-#undef TFEM_SRC_BINARY
-#undef TFEM_SRC_UNARY
+#undef TFEM_SRC_SET
 #pragma unroll
   for (int q = 0; q < QL; ++q) out[q] = s0[q];
 }

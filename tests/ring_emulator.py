@@ -80,12 +80,18 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         assert n_elem == 0 or local.max() < n_vert
         if conn is not None:  # the element's vertices, in the element's own local order
             assert np.array_equal(gid[local], conn[tile_elems])
-        fq_tile = None
+        facc_tile = None
         if source is not None:
+            # element form: f at the element's points from the tile-local coordinates, the three
+            # shares det_T g[T][i] added to the accumulators of the element's local vertices
             cx, cy = xy[local][..., 0], xy[local][..., 1]  # (n_elem, 3)
             xq = (np.outer(cx[:, 0], lam[0]) + np.outer(cx[:, 1], lam[1])) + np.outer(cx[:, 2], lam[2])
             yq = (np.outer(cy[:, 0], lam[0]) + np.outer(cy[:, 1], lam[1])) + np.outer(cy[:, 2], lam[2])
             fq_tile = source_program_eval(source[0], source[1], xq, yq)
+            det = (cx[:, 1] - cx[:, 0]) * (cy[:, 2] - cy[:, 0]) - (cx[:, 2] - cx[:, 0]) * (cy[:, 1] - cy[:, 0])
+            facc_tile = np.zeros(n_vert)
+            for i in range(3):
+                np.add.at(facc_tile, local[:, i], det * (fq_tile @ lamw[i]))
         rowstart = plan["rowstart"][row_off:row_off + n_own]
         for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
             if b > a:  # what the consecutive-vertex kernel takes from the descriptor
@@ -119,18 +125,17 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
                 diag += cs * dvec.dot(dvec) + mass_d * sdet
                 off[i] += -cs * dvec.dot(e[nxt]) + mass_o * sdet
                 off[nxt] += cs * dvec.dot(e[i]) + mass_o * sdet
-                if fvec is not None:
+                if fvec is not None and facc_tile is None:
                     elem, loc = int(tile_elems[se[i] & 0x3FF]), int(se[i] >> 10)
                     assert loc < 3
-                    values = fq_tile[se[i] & 0x3FF] if fq_tile is not None else fq[elem]
-                    facc += sdet * float(np.dot(values, lamw[loc]))
+                    facc += sdet * float(np.dot(fq[elem], lamw[loc]))
             targets = np.concatenate([rowstart[r] + pos[:k], [rowstart[r] + rec["dpos"][r]]])
             assert np.unique(targets).size == k + 1
             assert targets.max() < rowstart[r] + k + 1
             vals[targets] = np.concatenate([off, [diag]])
             writes[targets] += 1
             if fvec is not None:
-                fvec[gid[r]] = facc
+                fvec[gid[r]] = facc if facc_tile is None else facc_tile[r]
     if fvec is not None:
         return vals, writes, covered, fvec
     return vals, writes, covered

@@ -114,14 +114,15 @@ def test_fast_sin_cos_against_correctly_rounded_values():
     just_x = _native.SourceProgram()
     just_x.n_ops = 1
     just_x.ops[0] = forms.OPS["PUSH_X"]
+    just_x.consts[0] = 1.0
     x = eng.source_values(just_x).reshape(-1).cpu().numpy()
     assert np.abs(x - basis.integration_points[..., 0].reshape(-1).cpu().numpy()).max() <= 2.3e-16
     for scale in (1e-300, 1e-8, 1.0, math.pi / 2, math.pi, 7.0, 1e3, 1e6, 9.9e8):
         for op in ("SIN", "COS"):
             program = _native.SourceProgram()
-            program.n_ops = 3
-            program.ops[0], program.ops[1], program.ops[2] = forms.OPS["PUSH_X"], forms.OPS["MUL_C"], forms.OPS[op]
-            program.consts[1] = scale
+            program.n_ops = 2
+            program.ops[0], program.ops[1] = forms.OPS["PUSH_X"], forms.OPS[op]
+            program.consts[0], program.consts[1] = scale, 1.0
             got = eng.source_values(program).reshape(-1).cpu().numpy()
             arg = x * scale
             want = np.sin(arg) if op == "SIN" else np.cos(arg)
@@ -248,6 +249,7 @@ def test_invalid_programs_are_refused_by_the_launch():
     bad = _native.SourceProgram()
     bad.n_ops = 2
     bad.ops[0], bad.ops[1] = forms.OPS["PUSH_X"], forms.OPS["ADD"]
+    bad.consts[0] = 1.0
     with pytest.raises(ValueError, match="empty stack"):
         basis._engine.load_source(bad)
     with pytest.raises(ValueError, match="empty stack"):

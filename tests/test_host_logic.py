@@ -18,8 +18,8 @@ from p2rows_emulator import run_p2_plan
 
 #: 2 pi^2 sin(pi x) sin(pi y) as the tracer compiles it (tests/test_assembly.py:75-77)
 _SIN_SIN_PROGRAM = (
-    [orc.SRC_PUSH_X, orc.SRC_MUL_C, orc.SRC_SIN, orc.SRC_MUL_C, orc.SRC_PUSH_Y, orc.SRC_MUL_C, orc.SRC_SIN, orc.SRC_MUL],
-    [0.0, np.pi, 0.0, 2.0 * np.pi**2, 0.0, np.pi, 0.0, 0.0],
+    [orc.SRC_PUSH_X, orc.SRC_SIN, orc.SRC_PUSH_Y, orc.SRC_SIN, orc.SRC_MUL],
+    [np.pi, 2.0 * np.pi**2, np.pi, 1.0, 0.0],
 )
 
 
@@ -399,10 +399,11 @@ def test_tracer_recognises_the_reference_vocabulary():
     e = forms.trace(load, b, (1.0,), {})
     assert isinstance(e, forms.LinearExpr) and isinstance(e.coefficient, forms.SourceExpr) and e.flux is None
     names = [name for name, _ in forms.compile_ops(e.coefficient.node)]
-    assert names == ["PUSH_X", "MUL_C", "SIN", "MUL_C", "PUSH_Y", "MUL_C", "SIN", "MUL", "MUL_C"]
+    assert names == ["PUSH_X", "SIN", "PUSH_Y", "SIN", "MUL", "MUL_C"]
     assert torch.equal(e.materialize(), load(b, 1.0))  # the same torch operations in the same order
     program = e.coefficient.program()
-    assert program.n_ops == 9 and list(program.ops[:3]) == [forms.OPS["PUSH_X"], forms.OPS["MUL_C"], forms.OPS["SIN"]]
+    assert program.n_ops == 6 and list(program.ops[:3]) == [forms.OPS["PUSH_X"], forms.OPS["SIN"], forms.OPS["PUSH_Y"]]
+    assert list(program.consts[:2]) == [np.pi, 2.0 * np.pi**2]
     # coordinate columns by indexing; a tensor coefficient (evaluated by the caller)
     e = forms.trace(lambda basis: basis.v * basis.integration_points[..., [0]], b, (), {})
     assert isinstance(e, forms.LinearExpr) and e.coefficient.node == ("x",)

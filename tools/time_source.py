@@ -59,14 +59,23 @@ def main():
     nnz = int(eng.csr_structure()[1].shape[0])
     algo = 12 * ne + 16 * nv + 8 * nnz + 8 * nv
     poly = forms.compile_program(("add", ("mul", ("x",), ("y",)), ("c", 1.0)))
+    chain = ("x",)
+    for i in range(16):
+        chain = ("add", chain, ("c", 1.0 + i))
+    chain = forms.compile_program(chain)
+    one = forms.compile_program(("c", 1.0))
     rows = [
         ("K only", lambda: eng.bilinear(1.0, 0.0), algo - 8 * nv),
         ("K + f, fq from memory", lambda: eng.assemble_system(1.0, 0.0, fq), algo),
         ("K + f, program sin*sin", lambda: eng.assemble_system(1.0, 0.0, source=program), algo),
         ("K + f, program x*y+1", lambda: eng.assemble_system(1.0, 0.0, source=poly), algo),
+        ("K + f, program constant (1 op)", lambda: eng.assemble_system(1.0, 0.0, source=one), algo),
+        ("K + f, program x + 16 constants (17 ops)", lambda: eng.assemble_system(1.0, 0.0, source=chain), algo),
         ("f only, fq from memory", lambda: eng.load(fq), None),
         ("f only, program sin*sin", lambda: eng.load_source(program), None),
         ("tfem_source_eval sin*sin", lambda: eng.source_values(program), None),
+        ("tfem_source_eval constant (1 op)", lambda: eng.source_values(one), None),
+        ("tfem_source_eval 17 ops", lambda: eng.source_values(chain), None),
         ("torch: f(x_q) from cached points", lambda: rhs(*torch.split(basis.integration_points, 1, dim=-1)), None),
         ("API: integrate_bilinear_form(csr) + integrate_linear_form",
          lambda: (basis.integrate_bilinear_form(lambda b: b.v_grad @ b.v_grad.mT, layout="csr"), basis.integrate_linear_form(load)), algo),
