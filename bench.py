@@ -1,14 +1,22 @@
 """Benchmark of the assembly hot path: Melements/s assembled (global K + f).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one pass of the hot path over one mesh: P1 stiffness operator K (CSR values)
-and load vector f, integration order 3, fp64, from vertex coordinates + connectivity
-resident in HBM.  Workload at N = 1: mesh S(2236, 0.25, 0) = 9,999,392 elements (the
-10 M-element mesh BASELINE.json's target is quoted on).  For N > 1 every rank holds one
-such mesh strip of a [0,N]x[0,1] domain (weak scaling) and the shared-DoF rows are
-exchanged with an RCCL all-reduce (pytorch_fem_solver_amd/parallel.py).
+One step = one pass of the hot path over one mesh, from vertex coordinates + connectivity
+resident in HBM to the P1 stiffness operator K (CSR values) AND the load vector f of the
+reference's own source f(x, y) = 2 pi^2 sin(pi x) sin(pi y) (tests/test_assembly.py:75-84),
+integration order 3, fp64.  The source is not pre-evaluated: the tracer records the caller's
+expression once (pytorch_fem_solver_amd/basis/forms.py) and every step's launch evaluates it
+at its integration points (k_p1_rings, SRC instantiation) -- the per-call work of the
+reference's integrate_linear_form is inside the timed step.
+
+Workload at N = 1: mesh S(2236, 0.25, 0) = 9,999,392 elements (the 10 M-element mesh
+BASELINE.json's target is quoted on).  N > 1, --scaling weak (default): every rank holds one
+such strip of a [0,N]x[0,1] domain; --scaling strong: ONE S(2236) mesh cut into N element
+ranges along the Morton curve of the centroids (BASELINE config 4).  Either way the DoFs
+shared between ranks are summed with one RCCL all-reduce of a packed interface buffer
+(pytorch_fem_solver_amd/parallel.py) on a side stream.
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,7 +24,9 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -28,13 +38,14 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_TAG = "r02"
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.1 s of timed work behind 0.01 s of warm-up -- the first milliseconds after an
-    # idle device run at lower clocks (tools/time_steps.py: 176 us per step in steady state)
+    # defaults: 0.13 s of timed work behind 0.01 s of warm-up -- the first milliseconds after an
+    # idle device run at lower clocks
     p.add_argument("--steps", type=int, default=500)
     p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--probe-every", type=int, default=10,
@@ -42,12 +53,16 @@ def parse():
                    "of stream time per step when recorded around every launch)")
     p.add_argument("--grid", dest="n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
     p.add_argument("--order", type=int, default=3, help="integration order")
+    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     p.add_argument("--cpu-sample", type=int, default=2236, help="n of the CPU-baseline sample mesh")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | rings | tiles | atomic")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     p.add_argument("--no-other-configs", action="store_true",
-                   help="skip the short measurement of BASELINE.json's config 3 (P2, 1e6 elements)")
+                   help="skip the short measurements of the other configurations (P2; Delaunay meshes)")
+    p.add_argument("--delaunay-points", type=int, default=1_000_000,
+                   help="vertices of the Delaunay meshes of other_configs (5000000 = the ~1e7-element "
+                   "size of profiles/; generating it takes over a minute of host time)")
     return p.parse_args()
 
 
@@ -58,56 +73,79 @@ def algorithmic_bytes(n_elems, n_verts, nnz, with_load=True):
     return 12 * n_elems + 16 * n_verts + 8 * nnz + (8 * n_verts if with_load else 0)
 
 
-def measured_traffic(n, order, kernel, with_load):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_bench_pmc_summary.json, written by tools/summarize_pmc.py: 2 x FETCH_SIZE +
-    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), or None when no summary matches
-    the workload.  The instantiation is recognised by its name: the fifth template argument of
-    `k_p1_rings<double, SLOTS, MASS, CHUNK, Q, ...>` is Q, 0 for the matrix-only launch."""
-    path = os.path.join(REPO, "profiles", "r01_bench_pmc_summary.json")
+def rhs(x, y):  # tests/test_assembly.py:75-77
+    return 2.0 * math.pi**2 * torch.sin(math.pi * x) * torch.sin(math.pi * y)
+
+
+def load_form(basis):  # tests/test_assembly.py:79-84
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    return rhs(x, y) * basis.v
+
+
+def stiffness_form(basis):  # examples/example_fractures_fem.py:112-116
+    return basis.v_grad @ basis.v_grad.mT
+
+
+def source_sha():
+    """Digest of the kernel sources: profiles taken from other sources are not quoted."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "pytorch_fem_solver_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def template_args(kernel_name):
+    inside = kernel_name.split("<", 1)[1].rsplit(">", 1)[0]
+    return [t.strip() for t in inside.split(",")]
+
+
+def is_launch(kernel_name, kernel, with_load):
+    """`k_p1_rings<T, SLOTS, MASS, CHUNK, Q, DBG[, KMAT[, SRC]]>`: the fused launch of the step is
+    the fp64 instantiation with Q > 0 and SRC = true, the matrix-only one has Q = 0."""
+    if kernel + "<double" not in kernel_name:
+        return False
+    args = template_args(kernel_name)
+    q = int(args[4])
+    if not with_load:
+        return q == 0
+    return q > 0 and len(args) >= 8 and args[7] == "true" and args[6] == "true"
+
+
+def committed_profile(n, order, kernel):
+    """HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 rule of
+    MI355X_MICROARCH.md) and steady-state kernel durations from the committed rocprofv3 runs of
+    this command (profiles/r02_*; tools/profile_bench.sh) -- only when they were taken from the
+    kernel sources of this tree (digest stored with the summary) and on this workload."""
+    out = {"fused": {}, "k_only": {}}
     try:
-        with open(path) as fh:
+        with open(os.path.join(REPO, "profiles", f"{PROFILE_TAG}_bench_pmc_summary.json")) as fh:
             summary = json.load(fh)
         w = summary["workload"]
-        if (w["n"], w["order"]) != (n, order):
-            return None
+        if (w["n"], w["order"]) != (n, order) or summary.get("source_sha") != source_sha():
+            return out
         for name, entry in summary["kernels"].items():
-            if kernel + "<double" not in name:
-                continue
-            q = int(name.split("<", 1)[1].split(",")[4])  # k_p1_rings<T, SLOTS, MASS, CHUNK, Q, ...>
-            if (q > 0) == with_load:
-                return float(entry["hbm_traffic_bytes_per_launch"]["total"])
+            for key, with_load in (("fused", True), ("k_only", False)):
+                if is_launch(name, kernel, with_load):
+                    out[key]["traffic"] = float(entry["hbm_traffic_bytes_per_launch"]["total"])
+                    steady = entry.get("kernel_us_steady")
+                    if steady:
+                        out[key]["kernel_ms_rocprofv3"] = steady["mean"] * 1e-3
+                    util = entry.get("valu_utilisation")
+                    if util is not None:
+                        out[key]["valu_utilisation"] = util
     except (OSError, KeyError, ValueError, IndexError):
         pass
-    return None
-
-
-def profiled_kernel_ms(kernel, with_load):
-    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary
-    of this command (profiles/r01_bench_kernel_stats.csv), or None.  The HIP-event interval
-    around ONE launch (roofline.kernel_ms) also holds the launch and completion latency of the
-    dispatch (~10-15 us for this grid); the profiler's figure is the kernel alone."""
-    import csv
-
-    path = os.path.join(REPO, "profiles", "r01_bench_kernel_stats.csv")
-    try:
-        with open(path, newline="") as fh:
-            for row in csv.DictReader(fh):
-                name = row["Name"]
-                if kernel + "<double" not in name:
-                    continue
-                q = int(name.split("<", 1)[1].split(",")[4])
-                if (q > 0) == with_load:
-                    return float(row["AverageNs"]) * 1e-6
-    except (OSError, KeyError, ValueError, IndexError):
-        pass
-    return None
+    return out
 
 
 def cpu_baseline(n, order):
     """The C/OpenMP oracle (oracle/assembly_oracle.c: a port of the reference's op sequence,
-    one element per iteration) timed on this host's cores: local K + local f + scatter into
-    CSR values / vector -- the same work as one GPU step."""
+    one element per iteration) timed on this host's cores: f(x_q) at the integration points
+    (numpy, as the reference evaluates it with torch on every call), local K + local f +
+    scatter into CSR values / vector -- the same work as one GPU step."""
     import __graft_entry__ as ge
 
     ge.build_oracle()
@@ -120,10 +158,11 @@ def cpu_baseline(n, order):
     verts, tris = mesh["vertices"], mesh["triangles"]
     nv = verts.shape[0]
     _, colind, slots = symbolic_host(tris, nv)  # symbolic phase, not timed (as on the GPU)
-    fq = orc.source_sin_sin(c_oracle.points(verts, tris, order))[..., 0]
+    pts = c_oracle.points(verts, tris, order)   # cached by the reference's Basis, not timed
     best = float("inf")
     for _ in range(3):
         t0 = time.perf_counter()
+        fq = orc.source_sin_sin(pts)[..., 0]
         k_local, f_local = c_oracle.p1_local(verts, tris, order, 1.0, 0.0, fq)
         vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
         f = c_oracle.scatter_vector(f_local, tris, nv)
@@ -135,16 +174,29 @@ def cpu_baseline(n, order):
         "unit": "Melements/s",
         "cores": c_oracle.threads(),
         "kind": "port",
-        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order}, C/OpenMP oracle "
-        f"(oracle/assembly_oracle.c), best of 3",
+        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order} incl. f(x_q) (numpy, one "
+        f"thread) + C/OpenMP oracle (oracle/assembly_oracle.c), best of 3",
     }
 
 
-def p2_config3(device):
+def event_ms(fn, reps, batches=5):
+    """Median over `batches` of the mean launch-to-launch time of `reps` calls (HIP events)."""
+    out = []
+    for _ in range(batches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) / reps)
+    return float(np.median(out))
+
+
+def p2_config3():
     """BASELINE.json config 3 (P2, 6x6 blocks, S(707) = 999,698 elements) on this GPU: the
-    two launches of k_p2_rows (vertex rows, edge rows), timed with HIP events after the main
-    measurement.  Algorithmic bytes per SURVEY.md 8(d): 24 B conn + 16 B per vertex + 8 B per
-    CSR value."""
+    two launches of k_p2_rows (vertex rows, edge rows).  Algorithmic bytes per SURVEY.md 8(d):
+    24 B conn + 16 B per vertex + 8 B per CSR value."""
     import pytorch_fem_solver_amd as tf
     from pytorch_fem_solver_amd import meshgen
 
@@ -155,16 +207,7 @@ def p2_config3(device):
     for _ in range(10):
         eng.bilinear(1.0, 0.0)
     torch.cuda.synchronize()
-    batches = []  # median of five batches of ten launches (one host hiccup does not decide it)
-    for _ in range(5):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            eng.bilinear(1.0, 0.0)
-        b.record()
-        torch.cuda.synchronize()
-        batches.append(a.elapsed_time(b) / 10)
-    ms = float(np.median(batches))
+    ms = event_ms(lambda: eng.bilinear(1.0, 0.0), 10)
     ne, nv, nnz = mesh_np["triangles"].shape[0], mesh_np["vertices"].shape[0], int(vals.shape[0])
     algo = 24 * ne + 16 * nv + 8 * nnz
     return {
@@ -177,6 +220,52 @@ def p2_config3(device):
         "achieved": algo / (ms * 1e-3) / 1e9,
         "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
+
+
+def delaunay_configs(n_points, order):
+    """SURVEY 8(d) family D(N_v, seed): scipy Delaunay triangulation of a random point set, in
+    its native numbering (worst case for locality) and after Morton renumbering of the vertices
+    (what a caller who cares about speed does once per mesh): K alone and the fused K + f step."""
+    import pytorch_fem_solver_amd as tf
+    from pytorch_fem_solver_amd import meshgen
+    from pytorch_fem_solver_amd.basis import forms
+
+    native = meshgen.delaunay_square(n_points, 1)
+    meshes = {
+        "D_morton": meshgen.permute_mesh(native, vertex_order=meshgen.morton_order(native["vertices"])),
+        "D_native": native,
+    }
+    out = {}
+    for name, mesh_np in meshes.items():
+        t0 = time.perf_counter()
+        basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(1, order))
+        eng = basis._engine
+        program = forms.trace(load_form, basis, (), {}).coefficient.program()
+        vals = eng.bilinear(1.0, 0.0)
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        ne, nv, nnz = eng.n_elems, eng.n_dofs, int(vals.shape[0])
+        for _ in range(30):
+            eng.bilinear(1.0, 0.0)
+            eng.assemble_system(1.0, 0.0, source=program)
+        torch.cuda.synchronize()
+        k_ms = event_ms(lambda: eng.bilinear(1.0, 0.0), 20)
+        kf_ms = event_ms(lambda: eng.assemble_system(1.0, 0.0, source=program), 20)
+        algo_k, algo_kf = algorithmic_bytes(ne, nv, nnz, False), algorithmic_bytes(ne, nv, nnz, True)
+        rings = eng.ring_plan() if eng.kernel_name() == "k_p1_rings" else None
+        out[f"{name}_{ne / 1e6:.1f}M"] = {
+            "workload": f"Delaunay mesh of {nv} random points, {ne} elements, "
+            f"{'Morton-renumbered vertices' if name == 'D_morton' else 'native scipy numbering'}, order {order}",
+            "kernel": eng.kernel_name(),
+            "plan": None if rings is None else ("consecutive-vertex tiles" if rings["chunked"] else "Z-order tiles"),
+            "setup_ms": setup_ms,
+            "stiffness_only": {"kernel_ms": k_ms, "frac": algo_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "fused_K_f": {"kernel_ms": kf_ms, "value": ne / kf_ms / 1e3, "unit": "Melements/s",
+                          "frac": algo_kf / (kf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        del basis, eng, vals
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -201,34 +290,53 @@ def main():
 
     import pytorch_fem_solver_amd as tf
     from pytorch_fem_solver_amd import meshgen, parallel
+    from pytorch_fem_solver_amd.basis import forms
 
     if args.kernel != "auto":
         os.environ["TFEM_KERNEL"] = args.kernel
     torch.set_default_dtype(torch.float64)
     n = args.n
-    # rank r owns the strip [r, r+1] x [0, 1]; identical jitter pattern per strip so that
-    # the shared boundary column coincides (boundary vertices are never displaced)
-    mesh_np = meshgen.structured_rectangle(n, n, float(rank), float(rank + 1), 0.0, 1.0, jitter=0.25, seed=0)
+    strong = distributed and args.scaling == "strong"
+    if strong:
+        # ONE mesh for the whole job; rank r assembles the r-th range of the elements sorted
+        # along the Morton curve of their centroids (every rank derives the same partition)
+        global_mesh = meshgen.unit_square(n, 0.25, 0)
+        element_order, bounds = parallel.partition_elements(
+            global_mesh["vertices"], global_mesh["triangles"], world, "morton")
+        mesh_np, local_to_global = parallel.extract_shard(
+            global_mesh, element_order[bounds[rank]:bounds[rank + 1]])
+        total_elems = int(global_mesh["triangles"].shape[0])
+    else:
+        # rank r owns the strip [r, r+1] x [0, 1]; identical jitter pattern per strip so that
+        # the shared boundary column coincides (boundary vertices are never displaced)
+        mesh_np = meshgen.structured_rectangle(n, n, float(rank), float(rank + 1), 0.0, 1.0, jitter=0.25, seed=0)
+        total_elems = int(mesh_np["triangles"].shape[0]) * world
     n_elems = mesh_np["triangles"].shape[0]
     n_verts = mesh_np["vertices"].shape[0]
+    t_mesh = time.perf_counter()
 
     torch.set_default_device(device)
     mesh = tf.MeshTri(triangulation=mesh_np)
     basis = tf.Basis(mesh, tf.ElementTri(polynomial_order=1, integration_order=args.order))
     engine = basis._engine
-    _, colind, _ = engine.csr_structure()
+    rowptr, colind, _ = engine.csr_structure()
     nnz = int(colind.shape[0])
-    nq = engine.n_quad
+    # the caller's source, recorded once: every step evaluates it inside its launch
+    traced = forms.trace(load_form, basis, (), {})
+    program = traced.coefficient.program()
+    assert program is not None
+    engine.assemble_system(1.0, 0.0, source=program)  # builds the plans, first launch
+    torch.cuda.synchronize()
+    setup_ms = (time.perf_counter() - t_mesh) * 1e3  # symbolic phase + plans + device copies
 
-    # source values at the integration points: the user's f(x_q), evaluated by torch once
-    # (tests/test_assembly.py:75-84); the per-step hot path consumes them from HBM
-    import math
-
-    pts = engine.geometry()[2]
-    fq = (2.0 * math.pi**2 * torch.sin(math.pi * pts[..., 0]) * torch.sin(math.pi * pts[..., 1])).contiguous()
-    del pts
-
-    exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine) if distributed else None
+    exchange = None
+    if distributed and strong:
+        exchange = parallel.InterfaceExchange.from_partition(
+            global_mesh, element_order, bounds, rank, rowptr.cpu().numpy(), colind.cpu().numpy(),
+            local_to_global, device, torch.float64)
+        del global_mesh
+    elif distributed:
+        exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine)
     # the interface all-reduce of step i runs on a side stream and overlaps the assembly
     # launch of step i+1 (steps are independent; every step's exchange completes inside the
     # timed region, which ends with a device-wide synchronise)
@@ -248,10 +356,10 @@ def main():
 
     def step():
         if exchange is None:
-            return engine.assemble_system(1.0, 0.0, fq)  # one fused launch: K and f
+            return engine.assemble_system(1.0, 0.0, source=program)  # one fused launch: K and f
         slot = counter[0] % depth
         counter[0] += 1
-        vals, f = engine.assemble_system(1.0, 0.0, fq, out=pairs[slot])
+        vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot])
         return vals, f, slot
 
     def exchange_step(vals, f, slot):
@@ -262,10 +370,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # an idle device runs its first ~20 ms of this launch slower (profiles/r01_launch_series.log:
-    # 221 us per launch over the first 50, 186 over the next 50, 179 from then on), so the device
-    # is brought to its steady state with 170 of the same steps (30 ms) before the W warm-up steps
-    # the caller asked for; reported in config.device_warmup_steps
+    # an idle device runs its first ~20 ms slower (profiles/r01_launch_series.log), so it is
+    # brought to its steady state with a fixed number of the same steps (about 40 ms) before the W
+    # warm-up steps the caller asked for; reported in config.device_warmup_steps
     # (a fixed count, the same on every rank: the steps of an N > 1 run hold collectives)
     device_warmup_steps = 170
     for k in range(device_warmup_steps):
@@ -304,22 +411,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     k_ms = float(np.mean([starts[i].elapsed_time(ends[i]) for i in starts]))
-    # the stiffness-only launch (the kernel BASELINE.json's 60 % target is quoted on), timed
-    # after the measured region
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    engine.bilinear(1.0, 0.0)
-    s0.record()
-    for _ in range(30):
-        engine.bilinear(1.0, 0.0)
-    s1.record()
-    torch.cuda.synchronize()
-    k_only_ms = s0.elapsed_time(s1) / 30
 
     if rank == 0:
-        total_elems = n_elems * world
         ms_per_step = elapsed * 1e3 / args.steps
         algo = algorithmic_bytes(n_elems, n_verts, nnz)
+        algo_k = algorithmic_bytes(n_elems, n_verts, nnz, False)
         achieved = algo / (k_ms * 1e-3) / 1e9
+        profile = committed_profile(n, args.order, engine.kernel_name()) if world == 1 else {"fused": {}, "k_only": {}}
+        # the stiffness-only launch (the kernel BASELINE.json's 60 % target is quoted on): back to
+        # back (what a caller that re-assembles on a fixed mesh sees: its ~200 MB read set survives
+        # in the 256 MB memory-side cache) and cold (every launch behind 512 MB of unrelated writes)
+        engine.bilinear(1.0, 0.0)
+        torch.cuda.synchronize()
+        k_only_ms = event_ms(lambda: engine.bilinear(1.0, 0.0), 30, batches=3)
+        scrub = torch.empty(64 * 1024 * 1024)  # 512 MB
+        cold = []
+        for _ in range(10):
+            scrub.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            engine.bilinear(1.0, 0.0)
+            b.record()
+            torch.cuda.synchronize()
+            cold.append(a.elapsed_time(b))
+        del scrub
         line = {
             "metric": "Melements/s assembled (global K + f)",
             "value": total_elems / (elapsed / args.steps) / 1e6,
@@ -329,18 +444,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"P1 Poisson stiffness K (CSR) + load f, order {args.order}, "
-                f"mesh S({n},0.25,0) per GPU = {n_elems} elements, {n_verts} DoFs, nnz {nnz}",
+                "workload": f"P1 Poisson stiffness K (CSR) + load f of 2 pi^2 sin(pi x) sin(pi y) evaluated "
+                f"in the launch, order {args.order}, "
+                + (f"ONE mesh S({n},0.25,0) = {total_elems} elements cut into {world} Morton ranges"
+                   if strong else f"mesh S({n},0.25,0) per GPU = {n_elems} elements, {n_verts} DoFs, nnz {nnz}"),
                 "elements_per_gpu": n_elems,
-                "partition": "one unit-square strip per rank" if world > 1 else "single mesh",
+                "partition": ("element ranges of one mesh along the Morton curve" if strong else
+                              "one unit-square strip per rank") if world > 1 else "single mesh",
                 "kernel": engine.kernel_name(),
+                "source": "program recorded by the tracer (%d operations), evaluated per step inside the launch" % program.n_ops,
                 "device_warmup_steps": device_warmup_steps,
                 "probe_every": probe,
+                "setup_ms": setup_ms,
+                "interface_buffer_bytes": exchange.nbytes if exchange is not None else 0,
             },
             "roofline": {
                 "bound": "hbm",
@@ -349,32 +470,51 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, args.order, engine.kernel_name(), True),
+                "traffic": profile["fused"].get("traffic"),
                 "algorithmic_bytes_per_launch": algo,
                 "kernel_ms": k_ms,
-                "launch": "fused K + f (52 B/element algorithmic, SURVEY.md 8(d); the Q source values "
-                "fq the launch must read, 8 Q B/element, are not part of that figure)",
-                "algorithmic_bytes_incl_fq": algo + 8 * nq * n_elems,
-                "frac_incl_fq": (algo + 8 * nq * n_elems) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "launch": "fused K + f with the source evaluated in the launch (52 B/element algorithmic, "
+                "SURVEY.md 8(d)); the launch is bound by fp64 vector issue, not by HBM: DESIGN.md section 3",
                 "stiffness_only": {
                     "kernel_ms": k_only_ms,
-                    "traffic": measured_traffic(n, args.order, engine.kernel_name(), False),
-                    "algorithmic_bytes_per_launch": algorithmic_bytes(n_elems, n_verts, nnz, False),
-                    "achieved": algorithmic_bytes(n_elems, n_verts, nnz, False) / (k_only_ms * 1e-3) / 1e9,
-                    "frac": algorithmic_bytes(n_elems, n_verts, nnz, False) / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "cold_ms": float(np.median(cold)),
+                    "traffic": profile["k_only"].get("traffic"),
+                    "algorithmic_bytes_per_launch": algo_k,
+                    "achieved": algo_k / (k_only_ms * 1e-3) / 1e9,
+                    "frac": algo_k / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_cold": algo_k / (float(np.median(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 },
             },
         }
-        # what the HBM interface moved (PMC bytes of profiles/) over the live launch duration
-        if n == 2236 and args.order == 3:  # the profiled workload
-            line["roofline"]["kernel_ms_rocprofv3"] = profiled_kernel_ms(engine.kernel_name(), True)
-            line["roofline"]["stiffness_only"]["kernel_ms_rocprofv3"] = profiled_kernel_ms(engine.kernel_name(), False)
-        for obj, ms in ((line["roofline"], k_ms), (line["roofline"]["stiffness_only"], k_only_ms)):
+        for key, obj, ms in (("fused", line["roofline"], k_ms), ("k_only", line["roofline"]["stiffness_only"], k_only_ms)):
+            for extra in ("kernel_ms_rocprofv3", "valu_utilisation"):
+                if extra in profile[key]:
+                    obj[extra] = profile[key][extra]
             if obj["traffic"]:
                 obj["traffic_GBps"] = obj["traffic"] / (ms * 1e-3) / 1e9
                 obj["traffic_frac_of_peak"] = obj["traffic_GBps"] / HBM_PEAK_GBS
+        if world == 1:
+            line["roofline"]["profile_source"] = (
+                f"profiles/{PROFILE_TAG}_bench_pmc_summary.json (kernel sources {source_sha()})"
+                if profile["fused"] else "no committed profile of these kernel sources: traffic not quoted")
+            # the same work through the reference's public API, per call: tracer + two launches
+            def api_step():
+                basis.integrate_bilinear_form(stiffness_form, layout="csr")
+                basis.integrate_linear_form(load_form)
+
+            for _ in range(20):
+                api_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                api_step()
+            torch.cuda.synchronize()
+            line["api_ms_per_step"] = (time.perf_counter() - t1) * 1e3 / 100
+            line["api_note"] = ("integrate_bilinear_form(v_grad @ v_grad.mT, layout='csr') + integrate_linear_form("
+                                "f(x_q) * v) per call at this mesh: tracer, K launch, f launch with the source inside")
         if world == 1 and not args.no_other_configs:
-            line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3(device)}
+            line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3()}
+            line["other_configs"].update(delaunay_configs(args.delaunay_points, args.order))
         if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only
             torch.set_default_device("cpu")
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.order)

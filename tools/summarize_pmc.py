@@ -22,7 +22,23 @@ p.add_argument("--out", required=True)
 p.add_argument("--n", type=int, default=2236)
 p.add_argument("--order", type=int, default=3)
 p.add_argument("--command", default="")
+p.add_argument("--trace", default=None, help="output directory of a --kernel-trace --stats run (no counters): "
+               "steady-state durations = the last 40 % of every kernel's dispatches")
 args = p.parse_args()
+
+
+def source_sha():
+    """bench.source_sha: digest of the kernel sources the profile was taken from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch_fem_solver_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
 
 counters = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
 durations = defaultdict(list)
@@ -40,7 +56,22 @@ for d in args.pmc:
                     seen.add(key)
                     durations[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 
-out = {"command": args.command, "workload": {"n": args.n, "order": args.order}, "kernels": {}}
+steady = {}
+if args.trace:
+    per_kernel = defaultdict(list)
+    for path in glob.glob(os.path.join(args.trace, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if args.kernel in row["Kernel_Name"]:
+                    per_kernel[row["Kernel_Name"]].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    for name, rows in per_kernel.items():
+        rows.sort()
+        tail = sorted(d for _, d in rows[int(0.6 * len(rows)):])
+        steady[name] = {"dispatches": len(rows), "tail_dispatches": len(tail), "mean": sum(tail) / len(tail),
+                        "median": tail[len(tail) // 2], "min": tail[0], "max": tail[-1],
+                        "all_mean": sum(d for _, d in rows) / len(rows)}
+
+out = {"command": args.command, "workload": {"n": args.n, "order": args.order}, "source_sha": source_sha(), "kernels": {}}
 for name, cs in counters.items():
     entry = {"counters_per_dispatch": {c: {"dispatches": len(v), "mean": sum(v) / len(v)} for c, v in sorted(cs.items())}}
     ds = durations[name]
@@ -58,6 +89,12 @@ for name, cs in counters.items():
         }
         if mean("TCC_MISS_sum") is not None:
             entry["hbm_traffic_bytes_per_launch"]["cross_check_TCC_MISS_x128B"] = mean("TCC_MISS_sum") * 128.0
+    if name in steady:
+        entry["kernel_us_steady"] = steady[name]  # un-profiled-counter run, last 40 % of the dispatches
+    if mean("SQ_ACTIVE_INST_VALU") is not None and mean("GRBM_GUI_ACTIVE") is not None:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles with a vector instruction active, summed over the
+        # waves; one per SIMD can be active: 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 is the ceiling
+        entry["valu_utilisation"] = mean("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
     out["kernels"][name] = entry
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)
