@@ -98,7 +98,7 @@ def source_sha():
 
 
 def template_args(kernel_name):
-    inside = kernel_name.split("<", 1)[1].rsplit(">", 1)[0]
+    inside = kernel_name.split("<", 1)[1].split(">", 1)[0]  # the kernel's own (flat) argument list
     return [t.strip() for t in inside.split(",")]
 
 
