@@ -365,6 +365,30 @@ int tfem_p1_assemble_rings_source(const void *coords, int real_bytes, int64_t n_
                                   int64_t n_elems, void *fout, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * The VPINN residual linear form, fused (DEVICE; P1 on one 2-D mesh):
+ *   r_i = sum_T sum_q dx_q ( f(x_q) v_i(q) + flux_sign * grad v_i . g_q )
+ * = integrate_linear_form of `rhs(x, y) * v - v_grad @ gradient(points).mT`
+ * (examples/example_weak.py:64-75 with abstract_basis.py:95-112; flux_sign = -1 there).
+ *   fq (n_elems, Q) source values, or `source` (HOST) a source program, or neither
+ *   flux (n_elems, Q, 2) = g at the integration points, or NULL
+ *   out_local (3, n_elems): the element vectors entry-major (out[i * n_elems + e]); the global
+ *   vector follows from tfem_csr_gather with the gather map of the connectivity, as for
+ *   tfem_tri_load_vector in LOCAL-VECTOR mode (no atomics, the reference's accumulation order).
+ * backward: the adjoint, for the training step that differentiates through the form
+ * (example_weak.py:132-152): from the cotangent of r (n_verts entries)
+ *   grad_flux[e][q][k] = flux_sign * dx_q * sum_i cot[conn[e][i]] * (grad v_i)_k
+ *   grad_fq[e][q]      = dx_q * sum_i cot[conn[e][i]] * v_i(q)
+ * either may be NULL; every entry is written once, no atomics.
+ * ------------------------------------------------------------------------- */
+int tfem_p1_residual_local(const void *coords, int real_bytes, const void *conn, int idx_bytes,
+                           int64_t n_elems, int64_t n_verts, int quad_order, const void *fq,
+                           const tfem_source_program *source, const void *flux, double flux_sign,
+                           void *out_local, void *stream);
+int tfem_p1_residual_backward(const void *coords, int real_bytes, const void *conn, int idx_bytes,
+                              int64_t n_elems, int64_t n_verts, int quad_order, const void *cotangent,
+                              double flux_sign, void *grad_fq, void *grad_flux, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * P2 row plan (HOST, once per mesh) + P2 row kernels (DEVICE): alpha * stiffness +
  * beta * mass for the quadratic element in owner-computes ROW form (one lane per CSR
  * row of a vertex DoF or of an edge DoF, no atomics).  Same operation as

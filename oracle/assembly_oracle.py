@@ -310,6 +310,24 @@ def integrand_load(geo, source=source_sin_sin):
 # --------------------------------------------------------------------------- #
 
 
+def integrand_weak_residual(geo, flux, source=source_sin_sin, flux_sign=-1.0):
+    """f(x_q) * v - v_grad @ g.mT, examples/example_weak.py:64-75 (flux = g, (..., Q, 1, 2))."""
+    f = source(geo["integration_points"])  # (..., Q, 1, 1)
+    return f * geo["v"] + flux_sign * (geo["v_grad"] @ np.swapaxes(flux, -1, -2))
+
+
+def weak_residual_adjoint(geo, connectivity, cotangent, flux_sign=-1.0):
+    """What autograd derives from abstract_basis.py:95-112 for the residual form: the cotangents
+    of g (..., Q, 1, 2) and of f (..., Q, 1, 1) from the cotangent of the assembled vector."""
+    conn = np.asarray(connectivity).reshape(-1, connectivity.shape[-1]).astype(np.int64)
+    ct = np.asarray(cotangent).reshape(-1)[conn]  # (E, 3)
+    dx = geo["dx"]  # (E, Q, 1, 1)
+    grad_flux = flux_sign * dx * np.einsum("ei,eqik->eqk", ct, np.broadcast_to(
+        geo["v_grad"], (conn.shape[0], dx.shape[1]) + geo["v_grad"].shape[-2:]))[:, :, None, :]
+    grad_f = dx * np.einsum("ei,qi->eq", ct, geo["v"][..., 0])[:, :, None, None]
+    return grad_flux, grad_f
+
+
 def integrate_local(integrand, dx):
     """(integrand * dx).sum(-3), abstract_basis.py:83,104."""
     return (integrand * dx).sum(-3)

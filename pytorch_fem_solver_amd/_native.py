@@ -149,6 +149,16 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
          c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     ),
+    "tfem_p1_residual_local": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+         c_double, c_void_p, c_void_p],
+    ),
+    "tfem_p1_residual_backward": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_double, c_void_p,
+         c_void_p, c_void_p],
+    ),
     "tfem_csr_to_dense": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p],

@@ -65,6 +65,40 @@ class _FunctionalFunction(torch.autograd.Function):
         return grad_integrand.sum_to_size(ctx.in_shape).to(ctx.in_device), None
 
 
+class _ResidualFormFunction(torch.autograd.Function):
+    """The VPINN residual form ``f * v + s * v_grad @ g.mT`` (examples/example_weak.py:64-75), fused:
+    forward = tfem_p1_residual_local + gather, backward = tfem_p1_residual_backward; neither
+    direction materialises the (N_T, Q, 3, 1) integrand.  `coefficient` is a tensor (..., Q, 1, 1) or
+    None (then `program`, a source program, or no source at all); `flux` a tensor (..., Q, 1, 2)."""
+
+    @staticmethod
+    def forward(ctx, coefficient, flux, basis, program, flux_sign):
+        engine = basis._engine
+        fq = None
+        if coefficient is not None:
+            fq = basis._source_values(coefficient.detach().to(engine.device, engine.dtype))
+        ctx.basis, ctx.flux_sign = basis, flux_sign
+        ctx.coefficient_meta = None if coefficient is None else (coefficient.shape, coefficient.device)
+        ctx.flux_meta = (flux.shape, flux.device)
+        return engine.residual(fq, program, engine._flat_flux(flux), flux_sign)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        engine = ctx.basis._engine
+        want_fq = ctx.coefficient_meta is not None and ctx.needs_input_grad[0]
+        want_flux = ctx.needs_input_grad[1]
+        grad_fq, grad_flux = engine.residual_backward(grad_out, ctx.flux_sign, want_fq, want_flux)
+        lead = tuple(engine.lead_shape)
+        g_coefficient = g_flux = None
+        if want_fq:
+            shape, device = ctx.coefficient_meta
+            g_coefficient = grad_fq.reshape(lead + (engine.n_quad, 1, 1)).sum_to_size(shape).to(device)
+        if want_flux:
+            shape, device = ctx.flux_meta
+            g_flux = grad_flux.reshape(lead + (engine.n_quad, 1, 2)).sum_to_size(shape).to(device)
+        return g_coefficient, g_flux, None, None, None
+
+
 class AbstractBasis(abc.ABC):
     """Finite-element basis on a mesh (abstract_basis.py:10-40)."""
 
@@ -182,12 +216,30 @@ class AbstractBasis(abc.ABC):
                 values = self._source_values(coefficient)
                 if values is not None:
                     return self._engine._home(self._engine.load(values)).reshape(-1, 1)
+        if isinstance(expr, forms.LinearExpr) and expr.flux is not None and self._engine.supports_residual():
+            out = self._residual_form(expr)
+            if out is not None:
+                return self._engine._home(out).reshape(-1, 1)
         integrand = forms.materialize(expr)
         if integrand.requires_grad and torch.is_grad_enabled():
             out = _LinearFormFunction.apply(integrand, self)
         else:
             out = self._engine.reduce_linear(integrand.detach(), self._dx)
         return self._engine._home(out).reshape(-1, 1)
+
+    def _residual_form(self, expr):
+        """f * v + s * v_grad @ g.mT through the fused residual kernels, or None when the
+        operands do not have the reference's shapes (then torch evaluates the integrand)."""
+        engine = self._engine
+        if engine._flat_flux(expr.flux) is None:
+            return None
+        coefficient, program = expr.coefficient, None
+        if isinstance(coefficient, forms.SourceExpr):
+            program = coefficient.program()
+            coefficient = None if program is not None else coefficient.materialize()
+        if coefficient is not None and self._source_values(coefficient) is None:
+            return None
+        return _ResidualFormFunction.apply(coefficient, expr.flux, self, program, expr.flux_sign)
 
     def _source_values(self, coefficient):
         """(E, Q) source values if ``coefficient`` broadcasts to (..., Q, 1, 1), else None."""

@@ -705,6 +705,54 @@ class AssemblyEngine:
             )
         return fq
 
+    # ------------------------------------------------------------------ VPINN residual form
+    def supports_residual(self):
+        """The fused residual form f v + s grad v . g: P1 on one 2-D mesh, DoFs = vertices."""
+        return self.poly_order == 1 and self.supports_source() and self._host_conn_geo.dim() == 2
+
+    def _flat_flux(self, flux):
+        """(E, Q, 2) contiguous from a tensor broadcastable to (..., Q, 1, 2), or None."""
+        want = tuple(self.lead_shape) + (self.n_quad, 1, 2)
+        try:
+            if tuple(torch.broadcast_shapes(tuple(flux.shape), want)) != want:
+                return None
+        except RuntimeError:
+            return None
+        return flux.detach().to(self.device, self.dtype).expand(want).reshape(self.n_elems, self.n_quad, 2).contiguous()
+
+    def residual(self, fq, program, flux, flux_sign):
+        """(N_dof,) vector of sum_q dx (f v + flux_sign grad v . g): one tfem_p1_residual_local
+        launch + the gather.  fq (E, Q) or program or neither; flux (E, Q, 2) or None."""
+        d = self._inputs()
+        local = torch.empty(3 * self.n_elems, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self.lib.tfem_p1_residual_local(
+                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]), 4,
+                    self.n_elems, self.coords_per_mesh, self.quad_order, _native.ptr(fq),
+                    ctypes.byref(program) if program is not None else None, _native.ptr(flux),
+                    float(flux_sign), _native.ptr(local), self._stream(),
+                )
+            )
+        return self._gather_local_vector(local)
+
+    def residual_backward(self, cotangent, flux_sign, want_fq, want_flux):
+        """Cotangents of the source values (E, Q) and of the flux (E, Q, 2) from the cotangent of
+        the residual vector: one tfem_p1_residual_backward launch."""
+        d = self._inputs()
+        cot = cotangent.detach().to(self.device, self.dtype).reshape(-1).contiguous()
+        grad_fq = torch.empty((self.n_elems, self.n_quad), dtype=self.dtype, device=self.device) if want_fq else None
+        grad_flux = torch.empty((self.n_elems, self.n_quad, 2), dtype=self.dtype, device=self.device) if want_flux else None
+        with torch.cuda.device(self.device):
+            _native.check(
+                self.lib.tfem_p1_residual_backward(
+                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]), 4,
+                    self.n_elems, self.coords_per_mesh, self.quad_order, _native.ptr(cot),
+                    float(flux_sign), _native.ptr(grad_fq), _native.ptr(grad_flux), self._stream(),
+                )
+            )
+        return grad_fq, grad_flux
+
     def load_source(self, program, out=None):
         """(N_dof,) load vector of the source program: evaluated inside the ring launch where
         the ring plan applies, else tfem_source_eval + the kernels that read source values."""

@@ -357,3 +357,111 @@ def test_bilinear_form_with_history_is_refused_loudly():
     with pytest.raises(NotImplementedError, match="autograd history"):
         basis.integrate_bilinear_form(lambda b: theta * (b.v @ b.v_grad[..., [0]].mT))
     basis.integrate_bilinear_form(lambda b: theta.detach() * (b.v @ b.v_grad[..., [0]].mT))
+
+
+# ---------------------------------------------------------------------------------------
+# the VPINN residual form, fused (tfem_p1_residual_local / _backward)
+# ---------------------------------------------------------------------------------------
+def _grad_field(points):  # tests/golden/tools/make_golden.py grad_field
+    x, y = torch.split(points, 1, dim=-1)
+    return torch.cat([torch.cos(3.0 * x) * y, x * x - torch.sin(2.0 * y)], dim=-1)
+
+
+def _weak_residual(basis, grad):  # examples/example_weak.py:64-75
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    return rhs(x, y) * basis.v - (basis.v_grad @ grad(basis.integration_points).mT)
+
+
+@pytest.mark.parametrize(
+    "fixture,orders",
+    [("p1_square_n8.npz", (1, 2, 3, 4)), ("p1_square_n5_clockwise.npz", (3,)), ("p1_delaunay_170.npz", (3,))],
+)
+def test_residual_form_takes_the_fused_kernel_and_matches_the_reference(fixture, orders):
+    d = load_golden(fixture)
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    for order in orders:
+        basis = tf().Basis(mesh, tf().ElementTri(1, order))
+        eng = basis._engine
+        calls = []
+        original = eng.residual
+        eng.residual = lambda *a: calls.append(a[1] is not None) or original(*a)
+        r = basis.integrate_linear_form(_weak_residual, _grad_field)
+        assert calls == [True], "not the fused residual launch with the source program inside"
+        assert scaled_error(r.cpu(), d[f"out_q{order}_f_weak_residual"]) <= TOL
+        # the restated form (oracle, pinned by the same fixture on the CPU) on this launch's inputs
+        geo = orc.geometry(d["in_vertices"][d["in_triangles"]], 1, order)
+        flux = _grad_field(basis.integration_points).cpu().numpy()
+        local = orc.integrate_local(orc.integrand_weak_residual(geo, flux), geo["dx"])
+        want = orc.assemble_linear(local, d["in_triangles"], d["in_vertices"].shape[0])
+        assert scaled_error(r.cpu(), want) <= TOL
+
+
+@pytest.mark.parametrize("home", ["cuda", "cpu"])
+def test_residual_form_gradients_against_torch_and_the_restated_adjoint(home):
+    """d loss / d theta through the fused backward, for a network-like flux AND a coefficient
+    tensor with history, against the reference's expressions differentiated by torch."""
+    torch.set_default_device(home)
+    d = load_golden("p1_delaunay_170.npz")
+    mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
+    basis = tf().Basis(mesh, tf().ElementTri(1, 4))
+    # (no bias in the last layer: the gradient of the network output in the points does not see it)
+    net = torch.nn.Sequential(torch.nn.Linear(2, 6), torch.nn.Tanh(), torch.nn.Linear(6, 1, bias=False)).to(torch.float64)
+    amp = torch.tensor(1.7, requires_grad=True)
+
+    def gradient(points):  # model/neural_network.py:85-100
+        points.requires_grad_(True)
+        out = net(points)
+        return torch.autograd.grad([out], [points], [torch.ones_like(out)], create_graph=True)[0]
+
+    def residual(b, grad):
+        x, y = torch.split(b.integration_points, 1, dim=-1)
+        return (amp * rhs(x, y)) * b.v - (b.v_grad @ grad(b.integration_points).mT)
+
+    eng = basis._engine
+    calls = []
+    original = eng.residual_backward
+    eng.residual_backward = lambda *a: calls.append(a[2:]) or original(*a)
+    r = basis.integrate_linear_form(residual, gradient)
+    assert r.requires_grad and r.device.type == home
+    params = list(net.parameters()) + [amp]
+    grads = torch.autograd.grad((r * r).sum(), params)
+    assert calls == [(True, True)]  # cotangents of the coefficient tensor and of the flux, one launch
+    integrand = (residual(basis, gradient) * basis._dx).sum(-3)
+    ref = torch.zeros(basis._basis_parameters["linear_form_shape"]).index_put(
+        (basis._global_dofs4elements.reshape(-1).long(),), integrand.reshape(-1, 1), accumulate=True)
+    want = torch.autograd.grad((ref * ref).sum(), params)
+    assert scaled_error(r.detach().cpu(), ref.detach().cpu()) <= TOL
+    for g, w in zip(grads, want):
+        assert g.device.type == home and scaled_error(g.cpu(), w.cpu()) <= 1e-10
+    # the backward launch against the numpy restatement of the adjoint
+    cot = torch.linspace(-1.0, 2.0, eng.n_dofs)
+    g_fq, g_flux = original(cot, -1.0, True, True)
+    geo = orc.geometry(d["in_vertices"][d["in_triangles"]], 1, 4)
+    want_flux, want_f = orc.weak_residual_adjoint(geo, d["in_triangles"], cot.cpu().numpy())
+    assert scaled_error(g_flux.cpu(), want_flux[:, :, 0, :]) <= TOL
+    assert scaled_error(g_fq.cpu(), want_f[:, :, 0, 0]) <= TOL
+
+
+def test_residual_form_full_size_linearity_and_adjoint_identity():
+    """At 2e6 elements (S(1000)): r is linear in (f, g), and <cot, r(g)> = <grad_g, g> -- the
+    size-independent properties of the pair of launches."""
+    from pytorch_fem_solver_amd import meshgen
+
+    basis = tf().Basis(tf().MeshTri(meshgen.unit_square(1000, 0.25, 0)), tf().ElementTri(1, 3))
+    eng = basis._engine
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g1 = torch.randn(eng.n_elems, eng.n_quad, 2, generator=gen)
+    g2 = torch.randn(eng.n_elems, eng.n_quad, 2, generator=gen)
+    fq = torch.randn(eng.n_elems, eng.n_quad, generator=gen)
+    r1 = eng.residual(fq, None, g1, -1.0)
+    r2 = eng.residual(None, None, g2, -1.0)
+    r12 = eng.residual(fq, None, g1 + 2.0 * g2, -1.0)
+    assert scaled_error((r1 + 2.0 * r2).cpu(), r12.cpu()) <= 1e-12
+    cot = torch.randn(eng.n_dofs, generator=gen)
+    grad_fq, grad_flux = eng.residual_backward(cot, -1.0, True, True)
+    lhs = float(cot @ r1)
+    rhs_ = float((grad_flux * g1).sum() + (grad_fq * fq).sum())
+    assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), float((grad_flux * g1).abs().sum()))
+    # the load part alone equals the load vector of the same source values
+    r_f = eng.residual(fq, None, None, -1.0)
+    assert scaled_error(r_f.cpu(), eng.load(fq).cpu()) <= 1e-13

@@ -159,6 +159,39 @@ def test_fracture_assembly_m64():
     assert abs(np.abs(A.data).sum() - np.abs(d["out_A_vals"]).sum()) <= 1e-9 * np.abs(d["out_A_vals"]).sum()
 
 
+def _grad_field_np(points):  # tests/golden/tools/make_golden.py grad_field
+    x, y = points[..., [0]], points[..., [1]]
+    return np.concatenate([np.cos(3.0 * x) * y, x * x - np.sin(2.0 * y)], axis=-1)
+
+
+@pytest.mark.parametrize("fixture,orders", [("p1_square_n8.npz", (1, 2, 3, 4)), ("p1_delaunay_170.npz", (3,)),
+                                            ("p1_square_n5_clockwise.npz", (3,))])
+def test_weak_residual_form_and_its_adjoint(fixture, orders):
+    """The VPINN residual f v - v_grad @ g.mT (examples/example_weak.py:64-75) against the
+    reference's integrate_linear_form output, and the restated adjoint against finite differences
+    of the restated form (linear in g and f: exact up to rounding)."""
+    d = load_golden(fixture)
+    tris = d["in_triangles"]
+    n = d["in_vertices"].shape[0]
+    for order in orders:
+        geo = orc.geometry(_cells(d), 1, order)
+        flux = _grad_field_np(geo["integration_points"])
+        local = orc.integrate_local(orc.integrand_weak_residual(geo, flux), geo["dx"])
+        assert scaled_error(orc.assemble_linear(local, tris, n), d[f"out_q{order}_f_weak_residual"]) <= TOL
+        rng = np.random.default_rng(order)
+        cot = rng.standard_normal(n)
+        g_flux, g_f = orc.weak_residual_adjoint(geo, tris, cot)
+        # <cot, r(flux + h dflux)> - <cot, r(flux)> = h <g_flux, dflux>
+        dflux = rng.standard_normal(flux.shape)
+        r0 = orc.assemble_linear(local, tris, n).reshape(-1)
+        r1 = orc.assemble_linear(orc.integrate_local(orc.integrand_weak_residual(geo, flux + dflux), geo["dx"]), tris, n).reshape(-1)
+        assert abs(cot @ (r1 - r0) - (g_flux * dflux).sum()) <= 1e-11 * np.abs(g_flux * dflux).sum()
+        df = rng.standard_normal(geo["dx"].shape)
+        r2 = orc.assemble_linear(orc.integrate_local(
+            orc.integrand_weak_residual(geo, flux, source=lambda p: orc.source_sin_sin(p) + df), geo["dx"]), tris, n).reshape(-1)
+        assert abs(cot @ (r2 - r0) - (g_f * df).sum()) <= 1e-11 * np.abs(g_f * df).sum()
+
+
 def test_edge_interpolation_restatement():
     """oracle.edge_interpolate_p1 against the reference's Basis.interpolate(InteriorEdgesBasis, u)
     output (make_golden.py), with the reference's own edge -> cells table and edge points."""
