@@ -189,6 +189,32 @@ int tfem_edge_interpolate_p1_backward(const void *coords, int real_bytes, const 
                                       int n_points, const void *g_value, const void *g_grad,
                                       void *grad_u, int64_t n_verts, void *stream);
 
+/* The same adjoint WITHOUT atomics (fixed summation order, bitwise reproducible): one lane per
+ * vertex walks the (edge, side) pairs around it.  inc_ptr (n_verts + 1) / inc_side: for every
+ * vertex the entries 4 * (2 * edge + side) + local index of the vertex in that side's cell,
+ * ascending (DEVICE int64 arrays, built once per edge table by the caller). */
+int tfem_edge_interpolate_p1_backward_rows(const void *coords, int real_bytes, const int32_t *conn,
+                                           const int64_t *edge_cells, const void *points,
+                                           int64_t n_edges, int n_points, const void *g_value,
+                                           const void *g_grad, const int64_t *inc_ptr,
+                                           const int64_t *inc_side, void *grad_u, int64_t n_verts,
+                                           void *stream);
+
+/* FractureBasis.interpolate(InteriorEdgesFractureBasis, u) (fracture_basis.py:225-272): a P1
+ * DoF vector on both sides of every interior edge of every fracture.  All DEVICE:
+ *   coords2d (F, n_verts, 2), coords3d (F, n_verts, 3) = mesh["vertices", "coordinates_3d"],
+ *   conn (F, n_cells, 3) int32 per-fracture vertex ids, edge_cells (F, n_edges, 2) int64 per-
+ *   fracture cell ids, points (F, n_edges, n_points, 3) the edge basis's 3-D integration points,
+ *   pinv (F, 2, 3) = mesh["inv_jacobian_fracture_map"], u (n_u).
+ *   value (F, n_edges, 2, n_points), grad (F, n_edges, 2, 3).
+ * u is indexed with the PER-FRACTURE vertex ids of the cells, exactly as the reference does
+ * (fracture_basis.py:229-231) -- reproduced, not repaired. */
+int tfem_edge_interpolate_p1_fracture(const void *coords2d, const void *coords3d, int real_bytes,
+                                      const int32_t *conn, const int64_t *edge_cells, const void *points,
+                                      const void *pinv, int64_t n_fractures, int64_t n_verts,
+                                      int64_t n_cells, int64_t n_edges, int n_points, const void *u,
+                                      int64_t n_u, void *value, void *grad, void *stream);
+
 /* CSR -> dense (n_dofs, n_dofs) row-major, the layout integrate_bilinear_form
  * returns in the reference (abstract_basis.py:81).  dense is overwritten. */
 int tfem_csr_to_dense(const int64_t *rowptr, const int32_t *colind, const void *vals,

@@ -127,6 +127,16 @@ SIGNATURES = {
         [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
          c_int64, c_void_p],
     ),
+    "tfem_edge_interpolate_p1_backward_rows": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "tfem_edge_interpolate_p1_fracture": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+         c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
     "tfem_csr_gather_map": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "tfem_csr_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tfem_interface_pack": (

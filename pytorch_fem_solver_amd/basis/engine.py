@@ -297,11 +297,15 @@ class AssemblyEngine:
         n_edges, n_points = int(points.shape[0]), int(points.shape[1])
         if tuple(cells.shape) != (n_edges, 2) or points.dim() != 3 or points.shape[2] != 2:
             raise ValueError("edge interpolation: edge_cells (N_e, 2) and points (N_e, Q, 2) expected")
-        key = (cells.data_ptr(), n_edges)  # ids are checked once per table (two device syncs)
+        # ids are checked once per table (two device syncs): the verdict is remembered for the
+        # CALLER's tensor (identity and version), never for an address -- a freed device copy's
+        # address can come back for another table
+        key = (id(edge_cells), edge_cells._version, n_edges)
         if n_edges and key != self._edge_cells_checked:
             if int(cells.min()) < 0 or int(cells.max()) >= self.n_elems:
                 raise IndexError("edge interpolation: cell id outside the mesh")
             self._edge_cells_checked = key
+            self._edge_cells_keepalive = edge_cells  # the id stays this tensor's while we hold it
         return cells, points, n_edges, n_points
 
     def edge_interpolate(self, edge_cells, points, u, prepared=False):
@@ -329,9 +333,25 @@ class AssemblyEngine:
             )
         return value, grad
 
-    def edge_interpolate_backward(self, edge_cells, points, g_value, g_grad, prepared=False):
+    def edge_incidence(self, cells):
+        """(inc_ptr, inc_side) of tfem_edge_interpolate_p1_backward_rows for the device table
+        `cells` (N_e, 2): per vertex the entries 4 * side + local index, ascending.  Built with
+        torch on the device, once per table (kept by the caller)."""
+        conn = self._inputs()["conn_geo"].long()
+        sides = cells.reshape(-1)
+        verts = conn[sides]  # (2 N_e, 3)
+        codes = (4 * torch.arange(sides.numel(), device=cells.device)[:, None] + torch.arange(3, device=cells.device)).reshape(-1)
+        order = torch.argsort(verts.reshape(-1) * (4 * sides.numel() + 4) + codes)
+        counts = torch.bincount(verts.reshape(-1), minlength=self.coords_per_mesh)
+        ptr = torch.zeros(self.coords_per_mesh + 1, dtype=torch.int64, device=cells.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        return ptr.contiguous(), codes[order].contiguous()
+
+    def edge_interpolate_backward(self, edge_cells, points, g_value, g_grad, prepared=False, incidence=None):
         """Adjoint of edge_interpolate in u: (N_v,) on the compute device from the cotangents
-        g_value (N_e, 2, Q) and g_grad (N_e, 2, 2); one tfem_edge_interpolate_p1_backward launch."""
+        g_value (N_e, 2, Q) and g_grad (N_e, 2, 2).  With the incidence table of edge_incidence:
+        tfem_edge_interpolate_p1_backward_rows (no atomics, reproducible); without it
+        tfem_edge_interpolate_p1_backward (hardware atomics)."""
         d = self._inputs()
         if prepared:
             cells, n_edges, n_points = edge_cells, int(points.shape[0]), int(points.shape[1])
@@ -342,14 +362,62 @@ class AssemblyEngine:
         g_grad = self._pairs(g_grad.detach().to(dev, self.dtype).reshape(n_edges, 2, 2))
         grad_u = torch.empty(self.coords_per_mesh, dtype=self.dtype, device=dev)
         with torch.cuda.device(dev):
+            if incidence is not None:
+                _native.check(
+                    self.lib.tfem_edge_interpolate_p1_backward_rows(
+                        _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
+                        _native.ptr(cells), _native.ptr(points), n_edges, n_points, _native.ptr(g_value),
+                        _native.ptr(g_grad), _native.ptr(incidence[0]), _native.ptr(incidence[1]),
+                        _native.ptr(grad_u), self.coords_per_mesh, self._stream(),
+                    )
+                )
+            else:
+                _native.check(
+                    self.lib.tfem_edge_interpolate_p1_backward(
+                        _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
+                        _native.ptr(cells), _native.ptr(points), n_edges, n_points, _native.ptr(g_value),
+                        _native.ptr(g_grad), _native.ptr(grad_u), self.coords_per_mesh, self._stream(),
+                    )
+                )
+        return grad_u
+
+    def edge_interpolate_fracture(self, coords3d, edge_cells, points, u):
+        """FractureBasis.interpolate on the interior edges of every fracture: one
+        tfem_edge_interpolate_p1_fracture launch.  coords3d (F, N_v, 3), edge_cells (F, N_e, 2),
+        points (F, N_e, Q, 3); returns value (F, N_e, 2, Q) and grad (F, N_e, 2, 3)."""
+        if self.poly_order != 1 or not self.n_fractures:
+            raise NotImplementedError("fracture edge interpolation: P1 on a fracture mesh")
+        d = self._inputs()
+        dev = self.device
+        f, n_v = self.n_fractures, self.coords_per_mesh
+        n_cells = self.n_elems // f
+        cells = edge_cells.to(dev, torch.int64).contiguous()
+        n_edges = int(cells.shape[1])
+        points = points.detach().to(dev, self.dtype).reshape(f, n_edges, -1, 3).contiguous()
+        n_points = int(points.shape[2])
+        x3 = coords3d.detach().to(dev, self.dtype).reshape(f, n_v, 3).contiguous()
+        u = u.detach().to(dev, self.dtype).reshape(-1).contiguous()
+        if tuple(cells.shape) != (f, n_edges, 2):
+            raise ValueError("fracture edge interpolation: edge_cells (F, N_e, 2) expected")
+        if u.numel() < n_v:
+            raise IndexError("fracture edge interpolation: the vector is shorter than a fracture's vertex list")
+        key = (id(edge_cells), edge_cells._version, n_edges)
+        if n_edges and key != getattr(self, "_frac_cells_checked", None):
+            if int(cells.min()) < 0 or int(cells.max()) >= n_cells:
+                raise IndexError("fracture edge interpolation: cell id outside the fracture")
+            self._frac_cells_checked, self._frac_cells_keepalive = key, edge_cells
+        value = torch.empty((f, n_edges, 2, n_points), dtype=self.dtype, device=dev)
+        grad = torch.empty((f, n_edges, 2, 3), dtype=self.dtype, device=dev)
+        with torch.cuda.device(dev):
             _native.check(
-                self.lib.tfem_edge_interpolate_p1_backward(
-                    _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]),
-                    _native.ptr(cells), _native.ptr(points), n_edges, n_points, _native.ptr(g_value),
-                    _native.ptr(g_grad), _native.ptr(grad_u), self.coords_per_mesh, self._stream(),
+                self.lib.tfem_edge_interpolate_p1_fracture(
+                    _native.ptr(d["coords"]), _native.ptr(x3), self.real_bytes, _native.ptr(d["conn_geo"]),
+                    _native.ptr(cells), _native.ptr(points), _native.ptr(d["pinv"]), f, n_v, n_cells,
+                    n_edges, n_points, _native.ptr(u), u.numel(), _native.ptr(value), _native.ptr(grad),
+                    self._stream(),
                 )
             )
-        return grad_u
+        return value, grad
 
     def _home(self, tensor):
         """Result on the caller's device.  A host-resident caller gets large results through a

@@ -23,6 +23,10 @@ def _first_occurrence(inverse, n_unique, n_total):
 
 
 class FractureBasis(AbstractBasis):
+    #: False: interpolate on the interior edges evaluates the reference's expression sequence with
+    #: torch instead of launching tfem_edge_interpolate_p1_fracture (the tests compare the two)
+    edge_kernel = True
+
     def __init__(self, mesh, element):
         self.global_triangulation = self._build_global_triangulation(mesh)
         super().__init__(mesh, element)
@@ -133,6 +137,18 @@ class FractureBasis(AbstractBasis):
             n_local = self.mesh["cells", "vertices"].shape[-1]
             dof_ids = self._global_dofs4elements.reshape(n_frac, -1, 1, n_local)
             v, v_grad = self.v, self.v_grad
+        elif (basis.__class__ == InteriorEdgesFractureBasis and self.edge_kernel and tensor is not None
+              and torch.is_tensor(tensor) and not tensor.requires_grad and tensor.dtype == self._engine.dtype
+              and tensor.dim() == 2 and tensor.shape[-1] == 1 and self._element.polynomial_order == 1):
+            # one tfem_edge_interpolate_p1_fracture launch; shapes of the torch
+            # expressions below: value (F, N_e, 2, Q, 1, 1), gradient (F, N_e, 2, 1, 1, 3)
+            edge_mesh = basis.mesh
+            pts = basis.integration_points
+            value, grad = self._engine.edge_interpolate_fracture(
+                self.mesh["vertices", "coordinates_3d"], edge_mesh["interior_edges", "cells"], pts, tensor)
+            f, n_e, _, n_q = value.shape
+            return (self._engine._home(value).reshape(f, n_e, 2, n_q, 1, 1),
+                    self._engine._home(grad).reshape(f, n_e, 2, 1, 1, 3))
         elif basis.__class__ == InteriorEdgesFractureBasis:
             edge_mesh = basis.mesh
             cell_pairs = edge_mesh["interior_edges", "cells"]

@@ -20,22 +20,27 @@ class _EdgeInterpolateFunction(torch.autograd.Function):
     training loss; the reference gets the same derivative from autograd on basis.py:150-158)."""
 
     @staticmethod
-    def forward(ctx, u, engine, edge_cells, points):
-        ctx.engine, ctx.edge_cells, ctx.points = engine, edge_cells, points
+    def forward(ctx, u, engine, edge_cells, points, incidence=None):
+        ctx.engine, ctx.edge_cells, ctx.points, ctx.incidence = engine, edge_cells, points, incidence
         ctx.u_shape, ctx.u_device = u.shape, u.device
         value, grad = engine.edge_interpolate(edge_cells, points, u, prepared=True)
         return value.to(u.device), grad.to(u.device)
 
     @staticmethod
     def backward(ctx, g_value, g_grad):
-        grad_u = ctx.engine.edge_interpolate_backward(ctx.edge_cells, ctx.points, g_value, g_grad, prepared=True)
-        return grad_u.reshape(ctx.u_shape).to(ctx.u_device), None, None, None
+        # with the vertex -> (edge, side) incidence table: the row-form adjoint (no atomics)
+        grad_u = ctx.engine.edge_interpolate_backward(ctx.edge_cells, ctx.points, g_value, g_grad,
+                                                      prepared=True, incidence=ctx.incidence)
+        return grad_u.reshape(ctx.u_shape).to(ctx.u_device), None, None, None, None
 
 
 class Basis(AbstractBasis):
     #: False: Basis.interpolate on interior edges evaluates the reference's expression sequence
     #: with torch instead of launching tfem_edge_interpolate_p1 (the tests compare the two)
     edge_kernel = True
+    #: True: the adjoint of the edge interpolation runs in row form over the vertices (no atomics,
+    #: reproducible); False: hardware floating-point atomics (tfem_edge_interpolate_p1_backward)
+    edge_backward_rows = True
 
     def _compute_dofs(self, mesh, element):
         if element.polynomial_order == 1:
@@ -122,10 +127,11 @@ class Basis(AbstractBasis):
                 n_edges, n_points = pts.shape[0], pts.shape[-2]
                 cells, points, _, _ = self._engine._edge_inputs(
                     basis.mesh["interior_edges", "cells"], pts.detach().reshape(n_edges, n_points, 2))
-                staged = basis._edge_kernel_inputs = ((id(self._engine), pts.data_ptr()), cells, points)
-            _, cells, points = staged
+                incidence = self._engine.edge_incidence(cells) if self.edge_backward_rows else None
+                staged = basis._edge_kernel_inputs = ((id(self._engine), pts.data_ptr()), cells, points, incidence)
+            _, cells, points, incidence = staged
             n_edges, n_points = points.shape[0], points.shape[1]
-            val, grad = _EdgeInterpolateFunction.apply(values, self._engine, cells, points)
+            val, grad = _EdgeInterpolateFunction.apply(values, self._engine, cells, points, incidence)
             return val.reshape(n_edges, 2, n_points, 1, 1), grad.reshape(n_edges, 2, 1, 1, 2)
 
         kernel_ok = self.edge_kernel and on_edges and self._element.polynomial_order == 1
