@@ -319,7 +319,8 @@ def main():
     mesh = tf.MeshTri(triangulation=mesh_np)
     basis = tf.Basis(mesh, tf.ElementTri(polynomial_order=1, integration_order=args.order))
     engine = basis._engine
-    rowptr, colind, _ = engine.csr_structure()
+    csr = engine.csr_structure()
+    rowptr, colind = csr[0], csr[1]
     nnz = int(colind.shape[0])
     # the caller's source, recorded once: every step evaluates it inside its launch
     traced = forms.trace(load_form, basis, (), {})

@@ -75,6 +75,20 @@ int tfem_csr_symbolic_fill(const void *conn_host, int idx_bytes, int64_t n_elems
                            int n_local, int64_t n_dofs, const int64_t *rowptr_host,
                            int32_t *colind_host, int32_t *slots_host);
 
+/* The same in one pass (the pattern is built once, HOST, multi-threaded: TFEM_HOST_THREADS):
+ *   create : builds the pattern, returns a handle (library memory; release with _destroy) and nnz;
+ *            conn_host must stay valid until export
+ *   export : rowptr_host[n_dofs+1], colind_host[nnz] (caller-owned)
+ *   slots  : slots_host[n_elems*n_local*n_local] from the exported pattern -- only the scatter /
+ *            gather paths need it, the row-form plans do not */
+int tfem_csr_pattern_create(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                            int64_t n_dofs, void **pattern_out, int64_t *nnz_host);
+int tfem_csr_pattern_export(const void *pattern, int64_t *rowptr_host, int32_t *colind_host);
+void tfem_csr_pattern_destroy(void *pattern);
+int tfem_csr_symbolic_slots(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                            int64_t n_dofs, const int64_t *rowptr_host, const int32_t *colind_host,
+                            int32_t *slots_host);
+
 /* ------------------------------------------------------------------------- *
  * Geometry cache (DEVICE).  Replaces AbstractBasis._compute_integral_values
  * (abstract_basis.py:42-63) with Basis._compute_jacobian_map /

@@ -50,6 +50,12 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "tfem_csr_pattern_create": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "tfem_csr_pattern_export": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "tfem_csr_pattern_destroy": (None, [c_void_p]),
+    "tfem_csr_symbolic_slots": (
+        c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
     "tfem_tri_geometry": (
         c_int,
         [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_int]

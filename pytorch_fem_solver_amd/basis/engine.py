@@ -34,32 +34,47 @@ def _compute_device(home: torch.device) -> torch.device:
     )
 
 
+def pattern_host(conn_dof, n_dofs):
+    """CSR pattern of the operator (replaces the index tensors of basis.py:64-85): rowptr int64
+    (N+1), colind int32 (nnz), numpy in, numpy out; one pass of the multi-threaded host builder."""
+    lib = _native.load()
+    conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32, copy=False))
+    conn = conn.reshape(-1, conn.shape[-1])
+    e, n = conn.shape
+    handle, nnz = c_void_p(), ctypes.c_int64(0)
+    _native.check(lib.tfem_csr_pattern_create(c_void_p(conn.ctypes.data), 4, e, n, int(n_dofs),
+                                              ctypes.byref(handle), ctypes.byref(nnz)))
+    try:
+        rowptr = np.empty(int(n_dofs) + 1, dtype=np.int64)
+        colind = np.empty(max(nnz.value, 1), dtype=np.int32)
+        _native.check(lib.tfem_csr_pattern_export(handle, c_void_p(rowptr.ctypes.data), c_void_p(colind.ctypes.data)))
+    finally:
+        lib.tfem_csr_pattern_destroy(handle)
+    return rowptr, colind[: nnz.value]
+
+
+def slots_host(conn_dof, n_dofs, rowptr, colind):
+    """slots int32 (E*n*n): per element entry the CSR position it adds to (the scatter / gather
+    paths; the row-form plans do not need it)."""
+    lib = _native.load()
+    conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32, copy=False))
+    conn = conn.reshape(-1, conn.shape[-1])
+    e, n = conn.shape
+    slots = np.empty(max(e * n * n, 1), dtype=np.int32)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    colind = np.ascontiguousarray(colind, dtype=np.int32)
+    _native.check(lib.tfem_csr_symbolic_slots(c_void_p(conn.ctypes.data), 4, e, n, int(n_dofs),
+                                              c_void_p(rowptr.ctypes.data), c_void_p(colind.ctypes.data),
+                                              c_void_p(slots.ctypes.data)))
+    return slots[: e * n * n]
+
+
 def symbolic_host(conn_dof, n_dofs):
     """Host symbolic phase of the C ABI (replaces basis.py:64-85): CSR pattern of the
     operator and, per element entry, the CSR position it adds to.  numpy in, numpy out:
     rowptr int64 (N+1), colind int32 (nnz), slots int32 (E*n*n)."""
-    lib = _native.load()
-    conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32))
-    conn = conn.reshape(-1, conn.shape[-1])
-    e, n = conn.shape
-    rowptr = np.zeros(int(n_dofs) + 1, dtype=np.int64)
-    nnz = ctypes.c_int64(0)
-    _native.check(
-        lib.tfem_csr_symbolic_count(
-            c_void_p(conn.ctypes.data), 4, e, n, int(n_dofs),
-            c_void_p(rowptr.ctypes.data), ctypes.byref(nnz),
-        )
-    )
-    colind = np.zeros(max(nnz.value, 1), dtype=np.int32)
-    slots = np.zeros(max(e * n * n, 1), dtype=np.int32)
-    _native.check(
-        lib.tfem_csr_symbolic_fill(
-            c_void_p(conn.ctypes.data), 4, e, n, int(n_dofs),
-            c_void_p(rowptr.ctypes.data), c_void_p(colind.ctypes.data),
-            c_void_p(slots.ctypes.data),
-        )
-    )
-    return rowptr, colind[: nnz.value], slots[: e * n * n]
+    rowptr, colind = pattern_host(conn_dof, n_dofs)
+    return rowptr, colind, slots_host(conn_dof, n_dofs, rowptr, colind)
 
 
 #: default tile capacities: 45 KB of LDS per workgroup -> 3 workgroups per CU
@@ -151,7 +166,7 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
     try:
         layout = np.zeros(24, dtype=np.int64)
         _native.check(lib.tfem_ring_plan_sizes(handle, c_void_p(layout.ctypes.data)))
-        blob = np.zeros(int(layout[12]), dtype=np.uint8)
+        blob = np.empty(int(layout[12]), dtype=np.uint8)  # pack writes every byte
         _native.check(lib.tfem_ring_plan_pack(handle, c_void_p(blob.ctypes.data)))
     finally:
         lib.tfem_ring_plan_destroy(handle)
@@ -217,6 +232,29 @@ def p2_plan_host(conn_dof, n_verts, n_dofs, coords, rowptr, colind):
         "edge": {"desc": view(3, np.int32, 16 * z[1]), "rows": view(4, np.uint32, 4 * z[3]),
                  "vert_gid": view(5, np.int32, z[8])},
     }
+
+
+class _LazyTriple:
+    """(rowptr, colind, slots) whose third entry is built when somebody takes it."""
+
+    def __init__(self, rowptr, colind, make_slots):
+        self._head = (rowptr, colind)
+        self._make, self._slots = make_slots, None
+
+    def __getitem__(self, i):
+        if i in (0, 1):
+            return self._head[i]
+        if i in (2, -1):
+            if self._slots is None:
+                self._slots = self._make()
+            return self._slots
+        raise IndexError(i)
+
+    def __iter__(self):
+        return iter((self._head[0], self._head[1], self[2]))
+
+    def __len__(self):
+        return 3
 
 
 class AssemblyEngine:
@@ -433,19 +471,26 @@ class AssemblyEngine:
 
     # ------------------------------------------------------------------ symbolic phase
     def csr_structure(self):
-        """(rowptr int64, colind int32, slots int32 (E,n,n)) on the compute device."""
+        """(rowptr int64, colind int32, slots) on the compute device.  `slots` (int32 (E,n,n), the
+        CSR position of every element entry) is built on first use: only the scatter / gather
+        paths read it."""
         if self._csr is None:
             conn = self._host_conn_dof.cpu().numpy()
-            rowptr, colind, slots = symbolic_host(conn, self.n_dofs)
+            rowptr, colind = pattern_host(conn, self.n_dofs)
             self._csr_host = (rowptr, colind)
-            self._slots_host = slots
             dev = self.device
-            self._csr = (
-                torch.from_numpy(rowptr).to(dev),
-                torch.from_numpy(colind).to(dev),
-                torch.from_numpy(slots).to(dev),
-            )
+            self._csr = _LazyTriple(torch.from_numpy(rowptr).to(dev), torch.from_numpy(colind).to(dev), self._device_slots)
         return self._csr
+
+    def _host_slots(self):
+        if self._slots_host is None:
+            self.csr_structure()
+            rowptr, colind = self._csr_host
+            self._slots_host = slots_host(self._host_conn_dof.cpu().numpy(), self.n_dofs, rowptr, colind)
+        return self._slots_host
+
+    def _device_slots(self):
+        return torch.from_numpy(self._host_slots()).to(self.device)
 
     def tile_plan(self):
         """Device copy of the tile plan, or None when this basis cannot use it (P2,
@@ -560,7 +605,7 @@ class AssemblyEngine:
             self.csr_structure()
             nn = self.n_local * self.n_local
             nnz = int(self._csr_host[1].shape[0])
-            slots = np.ascontiguousarray(self._slots_host, dtype=np.int32)
+            slots = np.ascontiguousarray(self._host_slots(), dtype=np.int32)
             gptr = np.zeros(nnz + 1, dtype=np.int64)
             gsrc = np.zeros(max(slots.size, 1), dtype=np.int32)
             _native.check(self.lib.tfem_csr_gather_map(
@@ -615,8 +660,8 @@ class AssemblyEngine:
         return "k_p1_tiles_pipe" if self.tile_plan() is not None else "k_p1_bilinear_atomic"
 
     def wrap_csr(self, vals):
-        rowptr, colind, _ = self.csr_structure()
-        return CSRMatrix(rowptr, colind, vals, (self.n_dofs, self.n_dofs))
+        csr = self.csr_structure()
+        return CSRMatrix(csr[0], csr[1], vals, (self.n_dofs, self.n_dofs))
 
     def wrap_csr_home(self, vals):
         """The operator on the caller's device: the pattern is copied there once, the values
@@ -624,8 +669,8 @@ class AssemblyEngine:
         if self.home == self.device:
             return self.wrap_csr(vals)
         if getattr(self, "_csr_home", None) is None:
-            rowptr, colind, _ = self.csr_structure()
-            self._csr_home = (rowptr.to(self.home), colind.to(self.home))
+            csr = self.csr_structure()
+            self._csr_home = (csr[0].to(self.home), csr[1].to(self.home))
         return CSRMatrix(self._csr_home[0], self._csr_home[1], self._home(vals), (self.n_dofs, self.n_dofs))
 
     # ------------------------------------------------------------------ kernels
@@ -665,7 +710,8 @@ class AssemblyEngine:
             return self._assemble_rings(alpha, beta)
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
-        _, colind, slots = self.csr_structure()
+        csr = self.csr_structure()
+        colind = csr[1]
         nnz = int(colind.shape[0])
         if self.p2_plan() is not None:
             rows = self.p2_plan()
@@ -690,7 +736,7 @@ class AssemblyEngine:
                 self.lib.tfem_tri_bilinear_csr(
                     _native.ptr(d["coords"]), self.real_bytes, _native.ptr(d["conn_geo"]), 4,
                     self.n_elems, self.coords_per_mesh, self.poly_order, self.quad_order,
-                    float(alpha), float(beta), None if two_pass else _native.ptr(slots),
+                    float(alpha), float(beta), None if two_pass else _native.ptr(csr[2]),
                     _native.ptr(out), out_len,
                     _native.ptr(d["pinv"]), _native.ptr(d["fdet"]), self.n_fractures,
                     self.coords_per_mesh, self._stream(),
@@ -928,8 +974,8 @@ class AssemblyEngine:
         n = self.n_local
         flat, es, qs = self._flatten_integrand(integrand, dx.shape, (n, n))
         dxf = dx.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
-        _, colind, slots = self.csr_structure()
-        nnz = int(colind.shape[0])
+        csr = self.csr_structure()
+        nnz = int(csr[1].shape[0])
         two_pass = self.kernel != "atomic"
         out_len = n * n * self.n_elems if two_pass else nnz
         out = torch.empty(out_len, dtype=self.dtype, device=self.device)
@@ -937,7 +983,7 @@ class AssemblyEngine:
             _native.check(
                 self.lib.tfem_reduce_scatter_bilinear(
                     _native.ptr(flat), self.real_bytes, es, qs, _native.ptr(dxf), self.n_elems,
-                    self.n_quad, n, None if two_pass else _native.ptr(slots), _native.ptr(out),
+                    self.n_quad, n, None if two_pass else _native.ptr(csr[2]), _native.ptr(out),
                     out_len, self._stream(),
                 )
             )

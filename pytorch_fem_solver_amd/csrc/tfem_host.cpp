@@ -5,7 +5,13 @@
 #include <numeric>
 #include <vector>
 
+#include <chrono>
+#include <memory>
+#include <cstdio>
+#include <cstdlib>
+
 #include "tfem_common.hpp"
+#include "tfem_threads.hpp"
 
 namespace tfem {
 
@@ -120,53 +126,132 @@ namespace {
 
 template <typename I>
 int check_conn(const I *conn, int64_t count, int64_t n_dofs) {
-  for (int64_t k = 0; k < count; ++k) {
-    if (conn[k] < 0 || int64_t(conn[k]) >= n_dofs)
+  std::vector<int64_t> bad(size_t(host_threads()) + 1, -1);
+  parallel_for(count, [&](int64_t b, int64_t e, int t) {
+    for (int64_t k = b; k < e; ++k)
+      if (conn[k] < 0 || int64_t(conn[k]) >= n_dofs) {
+        bad[size_t(t)] = k;
+        return;
+      }
+  }, 1 << 16);
+  for (int64_t k : bad)  // pieces are ascending: the first hit is the smallest index
+    if (k >= 0)
       return fail(TFEM_ERR_INDEX_RANGE, "connectivity entry %lld = %lld outside [0, %lld)",
                   (long long)k, (long long)conn[k], (long long)n_dofs);
-  }
   return TFEM_OK;
 }
 
-// Per-row sorted unique column lists.  Row r receives, from every element that contains
-// DoF r, all n DoFs of that element (the pattern is symmetric, so the transposed scatter
-// convention does not change it).  bucket_ptr/bucket hold the duplicated lists.
+// DoF -> incident elements (CSR form; the order inside a DoF's list is the order the threads
+// arrived in -- callers that need it ascending sort the short lists).  Bucket sizes and bucket
+// filling with relaxed atomic counters.
 template <typename I>
-void build_rows(const I *conn, int64_t n_elems, int n, int64_t n_dofs,
-                std::vector<int64_t> &row_start, std::vector<int32_t> &cols,
-                std::vector<int32_t> &row_len) {
-  std::vector<int64_t> count(n_dofs + 1, 0);
-  for (int64_t k = 0; k < n_elems * n; ++k) count[int64_t(conn[k]) + 1] += n;
-  row_start.assign(n_dofs + 1, 0);
-  std::partial_sum(count.begin(), count.end(), row_start.begin());
-  cols.resize(size_t(row_start[n_dofs]));
-  std::vector<int64_t> cursor(row_start.begin(), row_start.end() - 1);
-  for (int64_t e = 0; e < n_elems; ++e) {
-    const I *c = conn + e * n;
-    for (int a = 0; a < n; ++a) {
-      int64_t &pos = cursor[int64_t(c[a])];
-      for (int b = 0; b < n; ++b) cols[size_t(pos++)] = int32_t(c[b]);
+void build_incidence(const I *conn, int64_t n_elems, int n, int64_t n_dofs, std::vector<int64_t> &ptr,
+                     std::unique_ptr<int32_t[]> &elems) {
+  std::vector<int64_t> count(size_t(n_dofs) + 1, 0);
+  parallel_for(n_elems * n, [&](int64_t b, int64_t e, int) {
+    for (int64_t k = b; k < e; ++k) __atomic_fetch_add(&count[size_t(conn[k]) + 1], int64_t(1), __ATOMIC_RELAXED);
+  }, 1 << 16);
+  ptr.assign(size_t(n_dofs) + 1, 0);
+  std::partial_sum(count.begin(), count.end(), ptr.begin());
+  elems.reset(new int32_t[size_t(std::max<int64_t>(ptr[size_t(n_dofs)], 1))]);  // first touched by the threads below
+  std::vector<int64_t> &cursor = count;
+  std::copy(ptr.begin(), ptr.end() - 1, cursor.begin());
+  parallel_for(n_elems, [&](int64_t b, int64_t e, int) {
+    for (int64_t el = b; el < e; ++el)
+      for (int a = 0; a < n; ++a)
+        elems[size_t(__atomic_fetch_add(&cursor[size_t(conn[el * n + a])], int64_t(1), __ATOMIC_RELAXED))] = int32_t(el);
+  }, 1 << 14);
+}
+
+// Sorted unique columns of row r: the DoFs of every element that contains DoF r (the pattern
+// is symmetric, so the transposed scatter convention does not change it).  `scratch` holds at
+// least n * (incident elements) entries; returns the row length.
+template <typename I>
+inline int row_columns(const I *conn, int n, const int32_t *first_elem, const int32_t *last_elem,
+                       std::vector<int32_t> &scratch) {
+  scratch.clear();
+  for (const int32_t *e = first_elem; e != last_elem; ++e) {
+    const I *c = conn + int64_t(*e) * n;
+    for (int k = 0; k < n; ++k) scratch.push_back(int32_t(c[k]));
+  }
+  std::sort(scratch.begin(), scratch.end());
+  return int(std::unique(scratch.begin(), scratch.end()) - scratch.begin());
+}
+
+// The CSR pattern between the calls of the handle interface (tfem_csr_pattern_*): incidence and
+// row pointers; the columns are written straight into the caller's array by export.
+struct CsrPattern {
+  std::vector<int64_t> inc_ptr, rowptr;
+  std::unique_ptr<int32_t[]> inc;
+  int64_t n_dofs = 0, nnz = 0, n_elems = 0;
+  int n = 0;
+};
+
+template <typename I>
+void pattern_rows(const I *conn, int64_t n_elems, int n, int64_t n_dofs, CsrPattern &p) {
+  const bool timing = std::getenv("TFEM_PLAN_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pattern]   %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  p.n_dofs = n_dofs;
+  p.n_elems = n_elems;
+  p.n = n;
+  build_incidence(conn, n_elems, n, n_dofs, p.inc_ptr, p.inc);
+  lap("DoF -> elements");
+  p.rowptr.assign(size_t(n_dofs) + 1, 0);
+  parallel_for(n_dofs, [&](int64_t b, int64_t e, int) {
+    std::vector<int32_t> scratch;
+    for (int64_t r = b; r < e; ++r)
+      p.rowptr[size_t(r) + 1] = row_columns(conn, n, p.inc.get() + p.inc_ptr[size_t(r)], p.inc.get() + p.inc_ptr[size_t(r) + 1], scratch);
+  }, 1 << 12);
+  for (int64_t r = 0; r < n_dofs; ++r) p.rowptr[size_t(r) + 1] += p.rowptr[size_t(r)];
+  p.nnz = p.rowptr[size_t(n_dofs)];
+  lap("row lengths");
+}
+
+template <typename I>
+void pattern_columns(const I *conn, const CsrPattern &p, const int64_t *rowptr, int32_t *colind) {
+  parallel_for(p.n_dofs, [&](int64_t b, int64_t e, int) {
+    std::vector<int32_t> scratch;
+    for (int64_t r = b; r < e; ++r) {
+      const int len = row_columns(conn, p.n, p.inc.get() + p.inc_ptr[size_t(r)], p.inc.get() + p.inc_ptr[size_t(r) + 1], scratch);
+      std::copy_n(scratch.data(), len, colind + rowptr[r]);
     }
-  }
-  row_len.resize(size_t(n_dofs));
-  for (int64_t r = 0; r < n_dofs; ++r) {
-    int32_t *first = cols.data() + row_start[r];
-    int32_t *last = cols.data() + row_start[r + 1];
-    std::sort(first, last);
-    row_len[size_t(r)] = int32_t(std::unique(first, last) - first);
-  }
+  }, 1 << 12);
+}
+
+// slots[e][i][j] -> position of (row conn[j], col conn[i]): basis.py:73-76 builds rows_idx
+// by tiling conn and cols_idx by repeating it, the value is local.reshape(-1).
+template <typename I>
+void fill_slots(const I *conn, int64_t n_elems, int n, const int64_t *rowptr, const int32_t *colind,
+                int32_t *slots) {
+  parallel_for(n_elems, [&](int64_t b, int64_t e, int) {
+    for (int64_t el = b; el < e; ++el) {
+      const I *c = conn + el * n;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const int64_t row = int64_t(c[j]);
+          const int32_t col = int32_t(c[i]);
+          const int32_t *first = colind + rowptr[row];
+          const int32_t *last = colind + rowptr[row + 1];
+          slots[(el * n + i) * n + j] = int32_t(std::lower_bound(first, last, col) - colind);
+        }
+    }
+  }, 1 << 12);
 }
 
 template <typename I>
 int symbolic_count(const I *conn, int64_t n_elems, int n, int64_t n_dofs, int64_t *rowptr,
                    int64_t *nnz) {
   if (int st = check_conn(conn, n_elems * n, n_dofs)) return st;
-  std::vector<int64_t> row_start;
-  std::vector<int32_t> cols, row_len;
-  build_rows(conn, n_elems, n, n_dofs, row_start, cols, row_len);
-  rowptr[0] = 0;
-  for (int64_t r = 0; r < n_dofs; ++r) rowptr[r + 1] = rowptr[r] + row_len[size_t(r)];
-  *nnz = rowptr[n_dofs];
+  CsrPattern p;
+  pattern_rows(conn, n_elems, n, n_dofs, p);
+  std::copy(p.rowptr.begin(), p.rowptr.end(), rowptr);
+  *nnz = p.nnz;
   if (*nnz >= (int64_t(1) << 31))
     return fail(TFEM_ERR_INDEX_RANGE, "nnz = %lld does not fit the int32 slot map",
                 (long long)*nnz);
@@ -177,29 +262,36 @@ template <typename I>
 int symbolic_fill(const I *conn, int64_t n_elems, int n, int64_t n_dofs, const int64_t *rowptr,
                   int32_t *colind, int32_t *slots) {
   if (int st = check_conn(conn, n_elems * n, n_dofs)) return st;
-  std::vector<int64_t> row_start;
-  std::vector<int32_t> cols, row_len;
-  build_rows(conn, n_elems, n, n_dofs, row_start, cols, row_len);
-  for (int64_t r = 0; r < n_dofs; ++r) {
-    if (rowptr[r + 1] - rowptr[r] != row_len[size_t(r)])
+  CsrPattern p;
+  pattern_rows(conn, n_elems, n, n_dofs, p);
+  for (int64_t r = 0; r <= n_dofs; ++r)
+    if (rowptr[r] != p.rowptr[size_t(r)])
       return fail(TFEM_ERR_INVALID_ARGUMENT, "rowptr does not belong to this connectivity");
-    std::copy_n(cols.data() + row_start[r], row_len[size_t(r)], colind + rowptr[r]);
+  pattern_columns(conn, p, rowptr, colind);
+  fill_slots(conn, n_elems, n, rowptr, colind, slots);
+  return TFEM_OK;
+}
+
+// The handle keeps a pointer to the caller's connectivity: it must stay alive until export.
+struct PatternHandle {
+  CsrPattern p;
+  const void *conn = nullptr;
+  int idx_bytes = 4;
+};
+
+template <typename I>
+int pattern_create(const I *conn, int64_t n_elems, int n, int64_t n_dofs, PatternHandle **out) {
+  if (int st = check_conn(conn, n_elems * n, n_dofs)) return st;
+  auto *h = new PatternHandle();
+  h->conn = conn;
+  h->idx_bytes = int(sizeof(I));
+  pattern_rows(conn, n_elems, n, n_dofs, h->p);
+  if (h->p.nnz >= (int64_t(1) << 31)) {
+    const long long nnz = h->p.nnz;
+    delete h;
+    return fail(TFEM_ERR_INDEX_RANGE, "nnz = %lld does not fit the int32 slot map", nnz);
   }
-  // slots[e][i][j] -> position of (row conn[j], col conn[i]): basis.py:73-76 builds
-  // rows_idx by tiling conn and cols_idx by repeating it, the value is local.reshape(-1).
-  for (int64_t e = 0; e < n_elems; ++e) {
-    const I *c = conn + e * n;
-    for (int i = 0; i < n; ++i) {
-      for (int j = 0; j < n; ++j) {
-        const int64_t row = int64_t(c[j]);
-        const int32_t col = int32_t(c[i]);
-        const int32_t *first = colind + rowptr[row];
-        const int32_t *last = colind + rowptr[row + 1];
-        const int32_t *hit = std::lower_bound(first, last, col);
-        slots[(e * n + i) * n + j] = int32_t(hit - colind);
-      }
-    }
-  }
+  *out = h;
   return TFEM_OK;
 }
 
@@ -283,6 +375,51 @@ int tfem_csr_symbolic_fill(const void *conn_host, int idx_bytes, int64_t n_elems
                                rowptr_host, colind_host, slots_host);
   return tfem::symbolic_fill(static_cast<const int64_t *>(conn_host), n_elems, n_local, n_dofs,
                              rowptr_host, colind_host, slots_host);
+}
+
+int tfem_csr_pattern_create(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                            int64_t n_dofs, void **pattern_out, int64_t *nnz_host) {
+  if (int st = tfem::check_symbolic_args(conn_host, idx_bytes, n_elems, n_local, n_dofs)) return st;
+  if (!pattern_out || !nnz_host) return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL output");
+  *pattern_out = nullptr;
+  tfem::PatternHandle *h = nullptr;
+  const int st = idx_bytes == 4
+                     ? tfem::pattern_create(static_cast<const int32_t *>(conn_host), n_elems, n_local, n_dofs, &h)
+                     : tfem::pattern_create(static_cast<const int64_t *>(conn_host), n_elems, n_local, n_dofs, &h);
+  if (st != TFEM_OK) return st;
+  *pattern_out = h;
+  *nnz_host = h->p.nnz;
+  return TFEM_OK;
+}
+
+int tfem_csr_pattern_export(const void *pattern, int64_t *rowptr_host, int32_t *colind_host) {
+  if (!pattern || !rowptr_host) return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  const auto *h = static_cast<const tfem::PatternHandle *>(pattern);
+  if (h->p.nnz > 0 && !colind_host) return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  std::copy(h->p.rowptr.begin(), h->p.rowptr.end(), rowptr_host);
+  if (h->idx_bytes == 4)
+    tfem::pattern_columns(static_cast<const int32_t *>(h->conn), h->p, rowptr_host, colind_host);
+  else
+    tfem::pattern_columns(static_cast<const int64_t *>(h->conn), h->p, rowptr_host, colind_host);
+  return TFEM_OK;
+}
+
+void tfem_csr_pattern_destroy(void *pattern) { delete static_cast<tfem::PatternHandle *>(pattern); }
+
+int tfem_csr_symbolic_slots(const void *conn_host, int idx_bytes, int64_t n_elems, int n_local,
+                            int64_t n_dofs, const int64_t *rowptr_host, const int32_t *colind_host,
+                            int32_t *slots_host) {
+  if (int st = tfem::check_symbolic_args(conn_host, idx_bytes, n_elems, n_local, n_dofs)) return st;
+  if (!rowptr_host || (!colind_host && rowptr_host[n_dofs] > 0) || (!slots_host && n_elems > 0))
+    return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (idx_bytes == 4) {
+    if (int st = tfem::check_conn(static_cast<const int32_t *>(conn_host), n_elems * n_local, n_dofs)) return st;
+    tfem::fill_slots(static_cast<const int32_t *>(conn_host), n_elems, n_local, rowptr_host, colind_host, slots_host);
+  } else {
+    if (int st = tfem::check_conn(static_cast<const int64_t *>(conn_host), n_elems * n_local, n_dofs)) return st;
+    tfem::fill_slots(static_cast<const int64_t *>(conn_host), n_elems, n_local, rowptr_host, colind_host, slots_host);
+  }
+  return TFEM_OK;
 }
 
 int tfem_csr_gather_map(const int32_t *slots_host, int64_t n_elems, int nn, int64_t nnz,

@@ -29,10 +29,14 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <vector>
+#include <chrono>
+#include <cstdio>
 
 #include "tfem_common.hpp"
+#include "tfem_threads.hpp"
 
 namespace tfem {
 
@@ -197,10 +201,333 @@ bool build_fan(const I *conn, int32_t v, const int32_t *adj_first, const int32_t
   return true;
 }
 
+// Small open-addressing map global id -> tile-local number (one per emitting thread; cleared by
+// bumping a generation counter).
+struct TileMap {
+  std::vector<int32_t> key, val;
+  std::vector<uint32_t> gen;
+  uint32_t now = 0;
+  uint32_t mask;
+  explicit TileMap(uint32_t capacity) : key(capacity), val(capacity), gen(capacity, 0), mask(capacity - 1) {}
+  void clear() {
+    if (++now == 0) {
+      std::fill(gen.begin(), gen.end(), 0u);
+      now = 1;
+    }
+  }
+  static uint32_t hash(int32_t k) { return uint32_t(k) * 2654435761u; }
+  // returns the slot of `k` (present or free)
+  uint32_t slot(int32_t k) const {
+    uint32_t s = (hash(k) >> 7) & mask;
+    while (gen[s] == now && key[s] != k) s = (s + 1) & mask;
+    return s;
+  }
+  bool has(int32_t k) const { return gen[slot(k)] == now; }
+  int32_t get(int32_t k) const { return val[slot(k)]; }
+  void put(int32_t k, int32_t v) {
+    const uint32_t s = slot(k);
+    gen[s] = now;
+    key[s] = k;
+    val[s] = v;
+  }
+};
+
+// What one tile owns: its rows in order, and which wave of the workgroup takes which of them.
+struct TileSpec {
+  std::vector<int32_t> owned;
+  int32_t wave_start[5] = {0, 0, 0, 0, 0};
+};
+
+// What the tiles of one thread add to the plan arrays (a thread takes a contiguous range of
+// tiles, so the plan arrays are the threads' arenas one after the other), and per tile where its
+// share starts inside the arena.
+struct TileArena {
+  std::vector<int32_t> vert_gid, rowstart, tile_elems;
+  std::vector<uint32_t> rows, row_ecodes, tile_tverts;
+};
+
+struct TileOut {
+  int64_t off_vert = 0, off_row = 0, off_elem = 0, off_tv = 0;  // arena-local
+  int32_t n_vert = 0, n_own = 0, n_elem = 0, elem_mode = 0, gid0[4] = {0, 0, 0, 0}, rs0[4] = {0, 0, 0, 0};
+  int32_t wave_start[5] = {0, 0, 0, 0, 0};
+  int status = TFEM_OK;
+  int32_t bad_vertex = -1, bad_len = 0, bad_k = 0;
+};
+
+struct EmitScratch {
+  TileMap verts{4096}, elems{8192};
+  std::vector<int32_t> fan_elem, fan_loc, elems_here;
+  Fan fan;
+};
+
+// Numbers the tile's vertices (owned rows first, in the order given, then the halo in order of
+// first reference) and writes its row records, element list, element vertex table and slot codes.
+template <typename I>
+void emit_tile(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const int64_t *rowptr,
+               const int32_t *colind, int slots, int words, bool elem_ranges, const TileSpec &spec,
+               EmitScratch &sc, TileArena &ar, TileOut &out) {
+  const std::vector<int32_t> &owned = spec.owned;
+  const int n_own = int(owned.size());
+  out.n_own = n_own;
+  for (int w = 0; w < 5; ++w) out.wave_start[w] = spec.wave_start[w];
+  out.off_vert = int64_t(ar.vert_gid.size());
+  out.off_row = int64_t(ar.rowstart.size());
+  out.off_elem = int64_t(ar.tile_elems.size());
+  out.off_tv = int64_t(ar.tile_tverts.size());
+  sc.verts.clear();
+  for (int l = 0; l < n_own; ++l) sc.verts.put(owned[size_t(l)], l);
+  ar.vert_gid.insert(ar.vert_gid.end(), owned.begin(), owned.end());
+  int next_local = n_own;
+  for (int l = 0; l < n_own; ++l) {
+    const int32_t u = owned[size_t(l)];
+    for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+      const int32_t w = colind[p];
+      if (!sc.verts.has(w)) {
+        sc.verts.put(w, next_local++);
+        ar.vert_gid.push_back(w);
+      }
+    }
+  }
+  out.n_vert = next_local;
+  sc.fan_elem.assign(size_t(n_own) * size_t(slots), -1);
+  sc.fan_loc.assign(size_t(n_own) * size_t(slots), 0);
+  sc.elems_here.clear();
+  sc.elems.clear();
+  Fan &fan = sc.fan;
+  for (int l = 0; l < n_own; ++l) {
+    const int32_t u = owned[size_t(l)];
+    const int len = int(rowptr[u + 1] - rowptr[u]);
+    if (!build_fan(conn, u, adj + adj_ptr[size_t(u)], adj + adj_ptr[size_t(u) + 1], fan)) {
+      out.status = TFEM_ERR_UNSUPPORTED;
+      out.bad_vertex = u;
+      out.bad_len = -1;
+      return;
+    }
+    if (len != (fan.k ? fan.k + 1 : 0) || fan.k > slots) {
+      out.status = TFEM_ERR_UNSUPPORTED;
+      out.bad_vertex = u;
+      out.bad_len = len;
+      out.bad_k = fan.k;
+      return;
+    }
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int32_t *first = colind + rowptr[u];
+    const int32_t *last = colind + rowptr[u + 1];
+    const uint32_t k = uint32_t(fan.k);
+    const uint32_t dpos = len ? uint32_t(std::lower_bound(first, last, u) - first) : 0u;
+    for (int i = 0; i < fan.k; ++i) {
+      const uint32_t lid = uint32_t(sc.verts.get(fan.nb[i]));
+      const uint32_t pos = uint32_t(std::lower_bound(first, last, fan.nb[i]) - first);
+      const uint32_t flag = uint32_t(fan.flag[i]);
+      w[i / 3] |= lid << (10 * (i % 3));
+      if (slots == 7) {
+        w[2] |= flag << (10 + 2 * i);
+        w[3] |= pos << (3 * i);
+      } else {
+        w[5] |= flag << (2 * i);
+        if (i < 8)
+          w[6] |= pos << (4 * i);
+        else
+          w[7] |= pos << (4 * (i - 8));
+      }
+    }
+    if (slots == 7) {
+      w[0] |= (k & 3u) << 30;
+      w[1] |= (k >> 2) << 30;
+      w[2] |= dpos << 24;
+    } else {
+      w[0] |= (k & 3u) << 30;
+      w[1] |= (k >> 2) << 30;
+      w[2] |= (dpos & 3u) << 30;
+      w[3] |= (dpos >> 2) << 30;
+    }
+    ar.rows.insert(ar.rows.end(), w, w + words);
+    ar.rowstart.push_back(int32_t(rowptr[u]));
+    for (int i = 0; i < fan.k; ++i)
+      if (fan.flag[i] != 0) {
+        sc.fan_elem[size_t(l) * size_t(slots) + size_t(i)] = fan.elem[i];
+        sc.fan_loc[size_t(l) * size_t(slots) + size_t(i)] = fan.loc[i];
+        if (!sc.elems.has(fan.elem[i])) {
+          sc.elems.put(fan.elem[i], 0);
+          sc.elems_here.push_back(fan.elem[i]);
+        }
+      }
+  }
+  // the tile's elements, ascending (coalesced source-value loads), and the slot codes
+  std::vector<int32_t> &elems_here = sc.elems_here;
+  std::sort(elems_here.begin(), elems_here.end());
+  const int32_t n_elem = int32_t(elems_here.size());
+  out.n_elem = n_elem;
+  for (int32_t j = 0; j < n_elem; ++j) sc.elems.put(elems_here[size_t(j)], j);
+  for (int32_t j = 0; j < n_elem; ++j) {
+    const I *c = conn + 3 * int64_t(elems_here[size_t(j)]);
+    ar.tile_tverts.push_back(uint32_t(sc.verts.get(int32_t(c[0]))) | uint32_t(sc.verts.get(int32_t(c[1]))) << 10 |
+                              uint32_t(sc.verts.get(int32_t(c[2]))) << 20);
+  }
+  // Element numberings with locality: the ascending list is a few runs of consecutive ids.
+  // Up to kRingElemRuns of them are stored as 16 ints -- first id of every run, then the
+  // number of elements up to and including every run (n_elem for the unused ones) -- and the
+  // kernel derives the ids (desc[18] = 1); otherwise the list itself (desc[18] = 0).
+  if (elem_ranges && n_elem > 2 * kRingElemRuns) {
+    int32_t start[kRingElemRuns], upto[kRingElemRuns];
+    int runs = 0;
+    for (int32_t j = 0; j < n_elem; ++j) {
+      if (j == 0 || elems_here[size_t(j)] != elems_here[size_t(j) - 1] + 1) {
+        if (++runs > kRingElemRuns) break;
+        start[runs - 1] = elems_here[size_t(j)];
+      }
+      upto[runs - 1] = j + 1;
+    }
+    if (runs <= kRingElemRuns) {
+      for (int r = runs; r < kRingElemRuns; ++r) {
+        start[r] = 0;
+        upto[r] = n_elem;
+      }
+      ar.tile_elems.insert(ar.tile_elems.end(), start, start + kRingElemRuns);
+      ar.tile_elems.insert(ar.tile_elems.end(), upto, upto + kRingElemRuns);
+      out.elem_mode = 1;
+    }
+  }
+  if (!out.elem_mode) ar.tile_elems.insert(ar.tile_elems.end(), elems_here.begin(), elems_here.end());
+  const int ewords = (12 * slots + 31) / 32;  // 12-bit codes, packed: 3 (7 slots) or 6 dwords
+  for (int l = 0; l < n_own; ++l) {
+    uint32_t ew[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < slots; ++i) {
+      uint32_t code = 0xFFFu;
+      if (sc.fan_elem[size_t(l) * size_t(slots) + size_t(i)] >= 0) {
+        const int32_t le = sc.elems.get(sc.fan_elem[size_t(l) * size_t(slots) + size_t(i)]);
+        code = le < 1023 ? uint32_t(le) | uint32_t(sc.fan_loc[size_t(l) * size_t(slots) + size_t(i)]) << 10 : 0xFFFu;
+      }
+      const int bit = 12 * i;
+      ew[bit / 32] |= code << (bit % 32);
+      if (bit % 32 > 20) ew[bit / 32 + 1] |= code >> (32 - bit % 32);
+    }
+    ar.row_ecodes.insert(ar.row_ecodes.end(), ew, ew + ewords);
+  }
+  for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
+    if (spec.wave_start[w] < spec.wave_start[w + 1]) {
+      out.gid0[w] = owned[size_t(spec.wave_start[w])];
+      out.rs0[w] = int32_t(rowptr[owned[size_t(spec.wave_start[w])]]);
+    }
+}
+
+// All tiles, in parallel; then the plan arrays in tile order.  Returns the status of the first
+// tile (in tile order) that failed.
+template <typename I>
+int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const int64_t *rowptr,
+              const int32_t *colind, bool elem_ranges, const std::vector<TileSpec> &specs, RingPlan &plan) {
+  const int64_t n_tiles = int64_t(specs.size());
+  std::vector<TileOut> outs(static_cast<size_t>(n_tiles));
+  const int max_threads = host_threads();
+  std::vector<TileArena> arenas(static_cast<size_t>(max_threads));
+  std::vector<int64_t> first_tile(size_t(max_threads) + 1, n_tiles);  // tile range of every thread
+  const int ewords = (12 * plan.slots + 31) / 32;
+  int64_t total_rows = 0;
+  for (const TileSpec &sp : specs) total_rows += int64_t(sp.owned.size());
+  parallel_for(n_tiles, [&](int64_t b, int64_t e, int t) {
+    first_tile[size_t(t)] = b;
+    TileArena &ar = arenas[size_t(t)];
+    const size_t rows_here = size_t(total_rows * (e - b) / std::max<int64_t>(n_tiles, 1)) + 1024;
+    ar.vert_gid.reserve(rows_here * 3 / 2);
+    ar.rowstart.reserve(rows_here);
+    ar.rows.reserve(rows_here * size_t(plan.words));
+    ar.row_ecodes.reserve(rows_here * size_t(ewords));
+    ar.tile_elems.reserve(rows_here / 4);
+    ar.tile_tverts.reserve(rows_here * 3);
+    EmitScratch sc;
+    for (int64_t k = b; k < e; ++k)
+      emit_tile(conn, adj_ptr, adj, rowptr, colind, plan.slots, plan.words, elem_ranges, specs[size_t(k)], sc, ar,
+                outs[size_t(k)]);
+  }, 8);
+  for (const TileOut &o : outs)
+    if (o.status != TFEM_OK) {
+      if (o.bad_len < 0)
+        return fail(TFEM_ERR_UNSUPPORTED, "the triangles around vertex %d do not form fans", o.bad_vertex);
+      return fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", o.bad_vertex, o.bad_len, o.bad_k);
+    }
+  // where every thread's arena starts inside the plan arrays
+  std::vector<int64_t> base_vert(size_t(max_threads) + 1, 0), base_row(size_t(max_threads) + 1, 0),
+      base_elem(size_t(max_threads) + 1, 0), base_tv(size_t(max_threads) + 1, 0);
+  for (int t = 0; t < max_threads; ++t) {
+    base_vert[size_t(t) + 1] = base_vert[size_t(t)] + int64_t(arenas[size_t(t)].vert_gid.size());
+    base_row[size_t(t) + 1] = base_row[size_t(t)] + int64_t(arenas[size_t(t)].rowstart.size());
+    base_elem[size_t(t) + 1] = base_elem[size_t(t)] + int64_t(arenas[size_t(t)].tile_elems.size());
+    base_tv[size_t(t) + 1] = base_tv[size_t(t)] + int64_t(arenas[size_t(t)].tile_tverts.size());
+  }
+  for (const TileOut &o : outs) {
+    plan.max_n_elem = std::max(plan.max_n_elem, o.n_elem);
+    if (o.n_elem > kRingElemCap) plan.elems_staged = false;
+    plan.max_n_halo = std::max(plan.max_n_halo, o.n_vert - o.n_own);
+    plan.max_n_vert = std::max(plan.max_n_vert, o.n_vert);
+    plan.max_n_own = std::max(plan.max_n_own, o.n_own);
+  }
+  if (base_vert[size_t(max_threads)] >= (int64_t(1) << 31) || base_elem[size_t(max_threads)] >= (int64_t(1) << 31) ||
+      base_tv[size_t(max_threads)] >= (int64_t(1) << 31))
+    return fail(TFEM_ERR_INDEX_RANGE, "ring plan too large for its int32 offsets");
+  plan.desc.assign(size_t(n_tiles) * kRingDescStride, 0);
+  plan.vert_gid.resize(size_t(base_vert[size_t(max_threads)]));
+  plan.rowstart.resize(size_t(base_row[size_t(max_threads)]));
+  plan.rows.resize(size_t(base_row[size_t(max_threads)]) * size_t(plan.words));
+  plan.row_ecodes.resize(size_t(base_row[size_t(max_threads)]) * size_t(ewords));
+  plan.tile_elems.resize(size_t(base_elem[size_t(max_threads)]));
+  plan.tile_tverts.resize(size_t(base_tv[size_t(max_threads)]));
+  {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < max_threads; ++t)
+      pool.emplace_back([&, t]() {
+        const TileArena &ar = arenas[size_t(t)];
+        std::copy(ar.vert_gid.begin(), ar.vert_gid.end(), plan.vert_gid.begin() + base_vert[size_t(t)]);
+        std::copy(ar.rowstart.begin(), ar.rowstart.end(), plan.rowstart.begin() + base_row[size_t(t)]);
+        std::copy(ar.rows.begin(), ar.rows.end(), plan.rows.begin() + base_row[size_t(t)] * plan.words);
+        std::copy(ar.row_ecodes.begin(), ar.row_ecodes.end(), plan.row_ecodes.begin() + base_row[size_t(t)] * ewords);
+        std::copy(ar.tile_elems.begin(), ar.tile_elems.end(), plan.tile_elems.begin() + base_elem[size_t(t)]);
+        std::copy(ar.tile_tverts.begin(), ar.tile_tverts.end(), plan.tile_tverts.begin() + base_tv[size_t(t)]);
+        // the thread's tiles: [first_tile[t], first tile of the next thread that got any)
+        int64_t stop = n_tiles;
+        for (int u = t + 1; u < max_threads; ++u)
+          if (first_tile[size_t(u)] < n_tiles) {
+            stop = first_tile[size_t(u)];
+            break;
+          }
+        for (int64_t k = first_tile[size_t(t)]; k < stop; ++k) {
+          const TileOut &o = outs[size_t(k)];
+          int32_t *d = plan.desc.data() + size_t(k) * kRingDescStride;
+          d[0] = int32_t(base_vert[size_t(t)] + o.off_vert);
+          d[1] = o.n_vert;
+          d[2] = int32_t(base_row[size_t(t)] + o.off_row);
+          d[3] = 0;
+          d[4] = o.wave_start[1];
+          d[5] = o.wave_start[2];
+          d[6] = o.wave_start[3];
+          d[7] = o.n_own;
+          for (int w = 0; w < 4; ++w) {
+            d[8 + w] = o.gid0[w];
+            d[12 + w] = o.rs0[w];
+          }
+          d[16] = int32_t(base_elem[size_t(t)] + o.off_elem);
+          d[17] = o.n_elem;
+          d[18] = o.elem_mode;
+          d[19] = int32_t(base_tv[size_t(t)] + o.off_tv);
+        }
+      });
+    for (std::thread &th : pool) th.join();
+  }
+  plan.n_tiles = n_tiles;
+  return TFEM_OK;
+}
+
 template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
                 bool chunk_mode, RingPlan &plan) {
+  const bool timing = std::getenv("TFEM_PLAN_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ring plan] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // TFEM_RING_ELEM_RANGES=0: every tile stores its element list (A/B of the range encoding)
   const char *ranges_env = std::getenv("TFEM_RING_ELEM_RANGES");
   const bool elem_ranges = !(ranges_env && ranges_env[0] == '0');
@@ -211,7 +538,6 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   plan.max_row_len = int32_t(longest);
   plan.slots = longest <= 8 ? 7 : 15;
   plan.words = longest <= 8 ? 4 : 8;
-  // ---- Z-order of the vertices ---------------------------------------------------------
   double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
   for (int64_t v = 0; v < n_verts; ++v)
     for (int c = 0; c < 2; ++c) {
@@ -219,189 +545,33 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       hi[c] = std::max(hi[c], coords[2 * v + c]);
     }
   const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
-  std::vector<std::pair<uint64_t, int32_t>> order(static_cast<size_t>(n_verts));
   const double scale = double(1u << 24) / span;
-  for (int64_t v = 0; v < n_verts; ++v) {
-    const uint64_t qx = std::min<uint64_t>(uint64_t((coords[2 * v] - lo[0]) * scale), (1u << 24) - 1);
-    const uint64_t qy = std::min<uint64_t>(uint64_t((coords[2 * v + 1] - lo[1]) * scale), (1u << 24) - 1);
-    order[size_t(v)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(v)};
-  }
-  std::sort(order.begin(), order.end());
-  // ---- vertex -> incident elements ------------------------------------------------------
+  lap("row lengths, bounding box");
+  // ---- vertex -> incident elements (ascending per vertex) ----------------------------------
+  // bucket sizes and filling with relaxed atomic counters, then every vertex's short list sorted:
+  // the result does not depend on the thread count
   std::vector<int64_t> adj_ptr(size_t(n_verts) + 1, 0);
-  for (int64_t k = 0; k < 3 * n_elems; ++k) adj_ptr[size_t(conn[k]) + 1]++;
-  std::partial_sum(adj_ptr.begin(), adj_ptr.end(), adj_ptr.begin());
-  std::vector<int32_t> adj(size_t(3 * n_elems));
+  {
+    std::vector<int64_t> count(size_t(n_verts) + 1, 0);
+    parallel_for(3 * n_elems, [&](int64_t b, int64_t e, int) {
+      for (int64_t k = b; k < e; ++k) __atomic_fetch_add(&count[size_t(conn[k]) + 1], int64_t(1), __ATOMIC_RELAXED);
+    }, 1 << 16);
+    std::partial_sum(count.begin(), count.end(), adj_ptr.begin());
+  }
+  std::unique_ptr<int32_t[]> adj_store(new int32_t[size_t(std::max<int64_t>(3 * n_elems, 1))]);
+  int32_t *adj_data = adj_store.get();
   {
     std::vector<int64_t> cur(adj_ptr.begin(), adj_ptr.end() - 1);
-    for (int64_t e = 0; e < n_elems; ++e)
-      for (int a = 0; a < 3; ++a) adj[size_t(cur[size_t(conn[3 * e + a])]++)] = int32_t(e);
+    parallel_for(n_elems, [&](int64_t b, int64_t e, int) {
+      for (int64_t el = b; el < e; ++el)
+        for (int a = 0; a < 3; ++a)
+          adj_data[size_t(__atomic_fetch_add(&cur[size_t(conn[3 * el + a])], int64_t(1), __ATOMIC_RELAXED))] = int32_t(el);
+    }, 1 << 14);
+    parallel_for(n_verts, [&](int64_t b, int64_t e, int) {
+      for (int64_t v = b; v < e; ++v) std::sort(adj_data + adj_ptr[size_t(v)], adj_data + adj_ptr[size_t(v) + 1]);
+    }, 1 << 14);
   }
-  // ---- tiles -----------------------------------------------------------------------------
-  std::vector<int32_t> vert_stamp(size_t(n_verts), -1), vert_local(size_t(n_verts), 0);
-  std::vector<int32_t> owned, fresh;
-  std::vector<int32_t> elem_stamp(size_t(n_elems), -1), elem_local(size_t(n_elems), 0);
-  std::vector<int32_t> fan_elem, fan_loc, elems_here;
-  int32_t wave_start[5] = {0, 0, 0, 0, 0};  // of the tile under construction
-  int32_t tile = 0;
-  Fan fan;
-  int status = TFEM_OK;
-  // vertices `u` would add to the local set of the tile under construction
-  auto collect_fresh = [&](int32_t u) {
-    if (vert_stamp[size_t(u)] != tile) fresh.push_back(u);
-    for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
-      const int32_t w = colind[p];
-      if (w != u && vert_stamp[size_t(w)] != tile) fresh.push_back(w);
-    }
-  };
-  // numbers the tile's vertices (owned rows first, in the order given, then the halo in order of
-  // first reference) and writes its row records
-  auto emit_tile = [&]() {
-    const int n_own = int(owned.size());
-    const int32_t vert_off = int32_t(plan.vert_gid.size());
-    const int32_t row_off = int32_t(plan.rowstart.size());
-    for (int l = 0; l < n_own; ++l) {
-      vert_local[size_t(owned[size_t(l)])] = l;
-      vert_stamp[size_t(owned[size_t(l)])] = -2 - tile;  // numbered
-    }
-    plan.vert_gid.insert(plan.vert_gid.end(), owned.begin(), owned.end());
-    int next_local = n_own;
-    for (int l = 0; l < n_own; ++l) {
-      const int32_t u = owned[size_t(l)];
-      for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
-        const int32_t w = colind[p];
-        if (vert_stamp[size_t(w)] == tile) {
-          vert_stamp[size_t(w)] = -2 - tile;
-          vert_local[size_t(w)] = next_local++;
-          plan.vert_gid.push_back(w);
-        }
-      }
-    }
-    fan_elem.assign(size_t(n_own) * size_t(plan.slots), -1);
-    fan_loc.assign(size_t(n_own) * size_t(plan.slots), 0);
-    elems_here.clear();
-    for (int l = 0; l < n_own; ++l) {
-      const int32_t u = owned[size_t(l)];
-      const int len = int(rowptr[u + 1] - rowptr[u]);
-      if (!build_fan(conn, u, adj.data() + adj_ptr[size_t(u)], adj.data() + adj_ptr[size_t(u) + 1], fan)) {
-        status = fail(TFEM_ERR_UNSUPPORTED, "the triangles around vertex %d do not form fans", u);
-        return;
-      }
-      if (len != (fan.k ? fan.k + 1 : 0) || fan.k > plan.slots) {
-        status = fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", u, len, fan.k);
-        return;
-      }
-      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int32_t *first = colind + rowptr[u];
-      const int32_t *last = colind + rowptr[u + 1];
-      const uint32_t k = uint32_t(fan.k);
-      const uint32_t dpos = len ? uint32_t(std::lower_bound(first, last, u) - first) : 0u;
-      for (int i = 0; i < fan.k; ++i) {
-        const uint32_t lid = uint32_t(vert_local[size_t(fan.nb[i])]);
-        const uint32_t pos = uint32_t(std::lower_bound(first, last, fan.nb[i]) - first);
-        const uint32_t flag = uint32_t(fan.flag[i]);
-        w[i / 3] |= lid << (10 * (i % 3));
-        if (plan.slots == 7) {
-          w[2] |= flag << (10 + 2 * i);
-          w[3] |= pos << (3 * i);
-        } else {
-          w[5] |= flag << (2 * i);
-          if (i < 8)
-            w[6] |= pos << (4 * i);
-          else
-            w[7] |= pos << (4 * (i - 8));
-        }
-      }
-      if (plan.slots == 7) {
-        w[0] |= (k & 3u) << 30;
-        w[1] |= (k >> 2) << 30;
-        w[2] |= dpos << 24;
-      } else {
-        w[0] |= (k & 3u) << 30;
-        w[1] |= (k >> 2) << 30;
-        w[2] |= (dpos & 3u) << 30;
-        w[3] |= (dpos >> 2) << 30;
-      }
-      plan.rows.insert(plan.rows.end(), w, w + plan.words);
-      plan.rowstart.push_back(int32_t(rowptr[u]));
-      for (int i = 0; i < fan.k; ++i)
-        if (fan.flag[i] != 0) {
-          fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] = fan.elem[i];
-          fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)] = fan.loc[i];
-          if (elem_stamp[size_t(fan.elem[i])] != tile) {
-            elem_stamp[size_t(fan.elem[i])] = tile;
-            elems_here.push_back(fan.elem[i]);
-          }
-        }
-    }
-    // the tile's elements, ascending (coalesced source-value loads), and the slot codes
-    std::sort(elems_here.begin(), elems_here.end());
-    const int32_t elem_off = int32_t(plan.tile_elems.size());
-    const int32_t n_elem = int32_t(elems_here.size());
-    const int32_t tvert_off = int32_t(plan.tile_tverts.size());
-    for (int32_t j = 0; j < n_elem; ++j) {
-      const I *c = conn + 3 * int64_t(elems_here[size_t(j)]);
-      plan.tile_tverts.push_back(uint32_t(vert_local[size_t(c[0])]) | uint32_t(vert_local[size_t(c[1])]) << 10 |
-                                 uint32_t(vert_local[size_t(c[2])]) << 20);
-    }
-    if (n_elem > kRingElemCap) plan.elems_staged = false;
-    for (int32_t j = 0; j < n_elem; ++j) elem_local[size_t(elems_here[size_t(j)])] = j;
-    // Element numberings with locality: the ascending list is a few runs of consecutive ids.
-    // Up to kRingElemRuns of them are stored as 16 ints -- first id of every run, then the
-    // number of elements up to and including every run (n_elem for the unused ones) -- and the
-    // kernel derives the ids (desc[18] = 1); otherwise the list itself (desc[18] = 0).
-    int32_t elem_mode = 0;
-    if (elem_ranges && n_elem > 2 * kRingElemRuns) {
-      int32_t start[kRingElemRuns], upto[kRingElemRuns];
-      int runs = 0;
-      for (int32_t j = 0; j < n_elem; ++j) {
-        if (j == 0 || elems_here[size_t(j)] != elems_here[size_t(j) - 1] + 1) {
-          if (++runs > kRingElemRuns) break;
-          start[runs - 1] = elems_here[size_t(j)];
-        }
-        upto[runs - 1] = j + 1;
-      }
-      if (runs <= kRingElemRuns) {
-        for (int r = runs; r < kRingElemRuns; ++r) {
-          start[r] = 0;
-          upto[r] = n_elem;
-        }
-        plan.tile_elems.insert(plan.tile_elems.end(), start, start + kRingElemRuns);
-        plan.tile_elems.insert(plan.tile_elems.end(), upto, upto + kRingElemRuns);
-        elem_mode = 1;
-      }
-    }
-    if (!elem_mode) plan.tile_elems.insert(plan.tile_elems.end(), elems_here.begin(), elems_here.end());
-    plan.max_n_elem = std::max(plan.max_n_elem, n_elem);
-    const int ewords = (12 * plan.slots + 31) / 32;  // 12-bit codes, packed: 3 (7 slots) or 6 dwords
-    for (int l = 0; l < n_own; ++l) {
-      uint32_t ew[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < plan.slots; ++i) {
-        uint32_t code = 0xFFFu;
-        if (fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)] >= 0) {
-          const int32_t le = elem_local[size_t(fan_elem[size_t(l) * size_t(plan.slots) + size_t(i)])];
-          code = le < 1023 ? uint32_t(le) | uint32_t(fan_loc[size_t(l) * size_t(plan.slots) + size_t(i)]) << 10 : 0xFFFu;
-        }
-        const int bit = 12 * i;
-        ew[bit / 32] |= code << (bit % 32);
-        if (bit % 32 > 20) ew[bit / 32 + 1] |= code >> (32 - bit % 32);
-      }
-      plan.row_ecodes.insert(plan.row_ecodes.end(), ew, ew + ewords);
-    }
-    int32_t d[kRingDescStride] = {vert_off, next_local, row_off, 0,
-                                  wave_start[1], wave_start[2], wave_start[3], n_own,
-                                  0, 0, 0, 0, 0, 0, 0, 0, elem_off, n_elem, elem_mode, tvert_off};
-    plan.max_n_halo = std::max(plan.max_n_halo, next_local - n_own);
-    for (int w = 0; w < 4; ++w)  // first vertex and first CSR entry of every wave's rows
-      if (wave_start[w] < wave_start[w + 1]) {
-        d[8 + w] = owned[size_t(wave_start[w])];
-        d[12 + w] = int32_t(rowptr[owned[size_t(wave_start[w])]]);
-      }
-    plan.desc.insert(plan.desc.end(), d, d + kRingDescStride);
-    plan.max_n_vert = std::max(plan.max_n_vert, next_local);
-    plan.max_n_own = std::max(plan.max_n_own, int32_t(n_own));
-    ++tile;
-  };
+  lap("vertex -> elements");
   auto reset_plan = [&]() {
     plan.desc.clear();
     plan.rows.clear();
@@ -409,16 +579,14 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.tile_elems.clear();
     plan.tile_tverts.clear();
     plan.row_ecodes.clear();
+    plan.vert_gid.clear();
     plan.max_n_elem = 0;
     plan.elems_staged = true;
-    std::fill(elem_stamp.begin(), elem_stamp.end(), -1);
-    plan.vert_gid.clear();
     plan.max_n_vert = plan.max_n_own = plan.max_n_halo = 0;
-    std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
-    tile = 0;
+    plan.n_tiles = 0;
   };
-  plan.rows.reserve(size_t(n_verts) * size_t(plan.words));
-  plan.rowstart.reserve(size_t(n_verts));
+  std::vector<int32_t> vert_stamp(size_t(n_verts), -1);
+  std::vector<TileSpec> specs;
 
   // ---- mode 1: a wave's 64 rows are 64 CONSECUTIVE vertices (one contiguous piece of the CSR
   // array per wave: the kernel's fast output path); a tile = up to own_cap / 64 such chunks that
@@ -448,20 +616,23 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     chunk_first.push_back(int32_t(n_verts));
     const int64_t n_chunks = int64_t(chunk_first.size()) - 1;
     std::vector<std::pair<uint64_t, int32_t>> corder(static_cast<size_t>(n_chunks));
-    for (int64_t c = 0; c < n_chunks; ++c) {
-      const int64_t v0 = chunk_first[size_t(c)], v1 = chunk_first[size_t(c) + 1];
-      double cx = 0, cy = 0;
-      for (int64_t v = v0; v < v1; ++v) {
-        cx += coords[2 * v];
-        cy += coords[2 * v + 1];
+    parallel_for(n_chunks, [&](int64_t b, int64_t e, int) {
+      for (int64_t c = b; c < e; ++c) {
+        const int64_t v0 = chunk_first[size_t(c)], v1 = chunk_first[size_t(c) + 1];
+        double cx = 0, cy = 0;
+        for (int64_t v = v0; v < v1; ++v) {
+          cx += coords[2 * v];
+          cy += coords[2 * v + 1];
+        }
+        cx /= double(v1 - v0);
+        cy /= double(v1 - v0);
+        const uint64_t qx = std::min<uint64_t>(uint64_t((cx - lo[0]) * scale), (1u << 24) - 1);
+        const uint64_t qy = std::min<uint64_t>(uint64_t((cy - lo[1]) * scale), (1u << 24) - 1);
+        corder[size_t(c)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(c)};
       }
-      cx /= double(v1 - v0);
-      cy /= double(v1 - v0);
-      const uint64_t qx = std::min<uint64_t>(uint64_t((cx - lo[0]) * scale), (1u << 24) - 1);
-      const uint64_t qy = std::min<uint64_t>(uint64_t((cy - lo[1]) * scale), (1u << 24) - 1);
-      corder[size_t(c)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(c)};
-    }
+    }, 256);
     std::sort(corder.begin(), corder.end());
+    lap("chunks + their curve order");
     chunked = true;
     // pass 1: group the chunks into tiles (neighbouring chunks along the curve while the local
     // vertices fit); pass 2: emit the tiles in the order of their first vertex, so that the
@@ -514,66 +685,84 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       if ((groups.size() & 255) == 0 && probe_local > 2 * probe_rows + 4096) chunked = false;
     }
     if (chunked && probe_local > 2 * n_verts) chunked = false;
+    lap("grouping chunks into tiles");
     if (chunked) {
       const char *ord = std::getenv("TFEM_RING_ORDER");
       if (!(ord && std::strcmp(ord, "curve") == 0))
         std::sort(groups.begin(), groups.end(),
                   [](const std::vector<int32_t> &x, const std::vector<int32_t> &y) { return x[0] < y[0]; });
-      std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
-      for (const std::vector<int32_t> &g : groups) {
-        owned.clear();
-        for (int w = 0; w < 5; ++w) {
-          wave_start[w] = int32_t(owned.size());  // one chunk per wave
-          if (w < int(g.size()))
-            for (int32_t v = chunk_first[size_t(g[size_t(w)])]; v < chunk_first[size_t(g[size_t(w)]) + 1]; ++v)
-              owned.push_back(v);
+      specs.resize(groups.size());
+      parallel_for(int64_t(groups.size()), [&](int64_t b, int64_t e, int) {
+        for (int64_t t = b; t < e; ++t) {
+          const std::vector<int32_t> &g = groups[size_t(t)];
+          TileSpec &spec = specs[size_t(t)];
+          for (int w = 0; w < 5; ++w) {
+            spec.wave_start[w] = int32_t(spec.owned.size());  // one chunk per wave
+            if (w < int(g.size()))
+              for (int32_t v = chunk_first[size_t(g[size_t(w)])]; v < chunk_first[size_t(g[size_t(w)]) + 1]; ++v)
+                spec.owned.push_back(v);
+          }
         }
-        // the tile's local vertices: stamped with the tile id, as emit_tile expects
-        for (int32_t u : owned) {
-          fresh.clear();
-          collect_fresh(u);
-          for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
-        }
-        emit_tile();
-        if (status != TFEM_OK) return status;
-      }
-    } else {
-      std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
+      }, 64);
+      const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
+      if (st != TFEM_OK) return st;
+      if (int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
+      if (!chunked) reset_plan();
     }
-    if (status != TFEM_OK) return status;
-    if (chunked && int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
-    if (!chunked) reset_plan();
+    lap("emitting tiles");
   }
   plan.chunked = chunked;
+  if (chunked) return TFEM_OK;
 
   // ---- mode 2: greedy tiling of the VERTICES along the Z-order curve (any numbering) ------------
+  std::vector<std::pair<uint64_t, int32_t>> order(static_cast<size_t>(n_verts));
+  parallel_for(n_verts, [&](int64_t b, int64_t e, int) {
+    for (int64_t v = b; v < e; ++v) {
+      const uint64_t qx = std::min<uint64_t>(uint64_t((coords[2 * v] - lo[0]) * scale), (1u << 24) - 1);
+      const uint64_t qy = std::min<uint64_t>(uint64_t((coords[2 * v + 1] - lo[1]) * scale), (1u << 24) - 1);
+      order[size_t(v)] = {ring_spread_bits(qx) | (ring_spread_bits(qy) << 1), int32_t(v)};
+    }
+  }, 4096);
+  std::sort(order.begin(), order.end());
+  lap("z-order sort of vertices");
+  std::fill(vert_stamp.begin(), vert_stamp.end(), -1);
+  specs.clear();
+  std::vector<int32_t> fresh;
   int64_t cursor = 0;
-  while (!chunked && cursor < n_verts) {
-    owned.clear();
+  int32_t tile = 0;
+  while (cursor < n_verts) {
+    TileSpec spec;
     int n_local = 0;
-    while (cursor < n_verts && int(owned.size()) < own_cap) {
+    while (cursor < n_verts && int(spec.owned.size()) < own_cap) {
       const int32_t u = order[size_t(cursor)].second;
+      // vertices `u` would add to the local set of the tile under construction
       fresh.clear();
-      collect_fresh(u);
+      if (vert_stamp[size_t(u)] != tile) fresh.push_back(u);
+      for (int64_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+        const int32_t w = colind[p];
+        if (w != u && vert_stamp[size_t(w)] != tile) fresh.push_back(w);
+      }
       if (n_local + int(fresh.size()) > vert_cap ||
-          n_local + int(fresh.size()) - int(owned.size()) - 1 > kRingHaloCapHost) {
-        if (owned.empty())
+          n_local + int(fresh.size()) - int(spec.owned.size()) - 1 > kRingHaloCapHost) {
+        if (spec.owned.empty())
           return fail(TFEM_ERR_UNSUPPORTED, "vertex %d alone exceeds the tile capacity", u);
         break;
       }
       for (int32_t w : fresh) vert_stamp[size_t(w)] = tile;
       n_local += int(fresh.size());
-      owned.push_back(u);
+      spec.owned.push_back(u);
       ++cursor;
     }
     // owned rows ascending (contiguous output runs), 64 per wave
-    std::sort(owned.begin(), owned.end());
-    for (int w = 0; w < 5; ++w) wave_start[w] = std::min<int32_t>(64 * w, int32_t(owned.size()));
-    emit_tile();
-    if (status != TFEM_OK) return status;
+    std::sort(spec.owned.begin(), spec.owned.end());
+    for (int w = 0; w < 5; ++w) spec.wave_start[w] = std::min<int32_t>(64 * w, int32_t(spec.owned.size()));
+    specs.push_back(std::move(spec));
+    ++tile;
   }
-  plan.n_tiles = tile;
-  return TFEM_OK;
+  lap("greedy tiling along the curve");
+  const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
+  lap("emitting tiles");
+  return st;
 }
 
 void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
@@ -657,14 +846,27 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   int64_t layout[kRingLayoutLen];
   ring_layout(*p, layout);
   auto *out = static_cast<unsigned char *>(blob_host);
-  std::memset(out, 0, size_t(layout[12]));
-  std::memcpy(out + layout[8], p->desc.data(), p->desc.size() * 4);
-  std::memcpy(out + layout[9], p->rows.data(), p->rows.size() * 4);
-  std::memcpy(out + layout[10], p->rowstart.data(), p->rowstart.size() * 4);
-  std::memcpy(out + layout[11], p->vert_gid.data(), p->vert_gid.size() * 4);
-  std::memcpy(out + layout[15], p->row_ecodes.data(), p->row_ecodes.size() * 4);
-  std::memcpy(out + layout[16], p->tile_elems.data(), p->tile_elems.size() * 4);
-  std::memcpy(out + layout[20], p->tile_tverts.data(), p->tile_tverts.size() * 4);
+  // the arrays, each cut into pieces for the threads; the padding between them and the 64 spare
+  // bytes at the end are zero
+  struct Part { int64_t off; const void *src; int64_t bytes; };
+  const Part parts[7] = {
+      {layout[8], p->desc.data(), int64_t(p->desc.size()) * 4},
+      {layout[9], p->rows.data(), int64_t(p->rows.size()) * 4},
+      {layout[10], p->rowstart.data(), int64_t(p->rowstart.size()) * 4},
+      {layout[11], p->vert_gid.data(), int64_t(p->vert_gid.size()) * 4},
+      {layout[15], p->row_ecodes.data(), int64_t(p->row_ecodes.size()) * 4},
+      {layout[16], p->tile_elems.data(), int64_t(p->tile_elems.size()) * 4},
+      {layout[20], p->tile_tverts.data(), int64_t(p->tile_tverts.size()) * 4},
+  };
+  for (const Part &part : parts) {
+    const int64_t padded = (part.bytes + 15) & ~int64_t(15);
+    std::memset(out + part.off + part.bytes, 0, size_t(padded - part.bytes));
+    if (part.bytes == 0) continue;
+    parallel_for(part.bytes, [&](int64_t b, int64_t e, int) {
+      std::memcpy(out + part.off + b, static_cast<const unsigned char *>(part.src) + b, size_t(e - b));
+    }, 1 << 20);
+  }
+  std::memset(out + layout[12] - 64, 0, 64);
   return TFEM_OK;
 }
 

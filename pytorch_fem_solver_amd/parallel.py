@@ -211,8 +211,8 @@ class InterfaceExchange:
         and the n+1 vector entries."""
         n = int(round(np.sqrt(mesh["triangles"].shape[0] // 2)))
         nvx = n + 1
-        rowptr, colind, _ = engine.csr_structure()
-        rowptr, colind = rowptr.cpu().numpy(), colind.cpu().numpy()
+        csr = engine.csr_structure()
+        rowptr, colind = csr[0].cpu().numpy(), csr[1].cpu().numpy()
         iy = np.arange(nvx, dtype=np.int64)
         per_k = nvx + 2 * n
         k_idx, k_pos, f_idx, f_pos = [], [], [], []

@@ -649,3 +649,45 @@ def test_bench_reads_the_committed_profiles():
         assert algo <= traffic <= 1.5 * algo
         assert 0.05 <= duration <= 0.40  # ms
     assert bench.committed_profile(100, 3, "k_p1_rings") == {"fused": {}, "k_only": {}}  # another workload
+
+
+def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest():
+    """The once-per-mesh builders (CSR pattern, slot map, ring plan) are multi-threaded
+    (csrc/tfem_threads.hpp): 1, 3 and the default number of threads give identical bytes, and the
+    bytes are the ones the sequential round-1 builder produced for these meshes (digests taken
+    from that build before the builders were restructured)."""
+    import hashlib
+
+    from pytorch_fem_solver_amd import meshgen
+    from pytorch_fem_solver_amd.basis.engine import ring_plan_host, symbolic_host
+
+    delaunay = meshgen.delaunay_square(30000, 3)
+    cases = {
+        "S300": (meshgen.unit_square(300, 0.25, 0), "edd742215b8f66d5", "9b34763e1a02eab9"),
+        "Dmorton": (meshgen.permute_mesh(delaunay, vertex_order=meshgen.morton_order(delaunay["vertices"])),
+                    "d3d38becab193360", None),
+        "Dnative": (delaunay, "d789ebac29155b24", None),
+    }
+    saved = os.environ.get("TFEM_HOST_THREADS")
+    try:
+        for name, (mesh, plan_digest, pattern_digest) in cases.items():
+            nv = mesh["vertices"].shape[0]
+            seen = set()
+            for threads in ("1", "3", None):
+                if threads is None:
+                    os.environ.pop("TFEM_HOST_THREADS", None)
+                else:
+                    os.environ["TFEM_HOST_THREADS"] = threads
+                rowptr, colind, slots = symbolic_host(mesh["triangles"], nv)
+                plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind)
+                sym = hashlib.sha256(rowptr.tobytes() + colind.tobytes() + slots.tobytes()).hexdigest()[:16]
+                seen.add((hashlib.sha256(plan["blob"].tobytes()).hexdigest()[:16], sym))
+            assert len(seen) == 1, name
+            got_plan, got_sym = next(iter(seen))
+            assert got_plan == plan_digest, name
+            assert pattern_digest is None or got_sym == pattern_digest
+    finally:
+        if saved is None:
+            os.environ.pop("TFEM_HOST_THREADS", None)
+        else:
+            os.environ["TFEM_HOST_THREADS"] = saved
