@@ -104,14 +104,14 @@ def template_args(kernel_name):
 
 def is_launch(kernel_name, kernel, with_load):
     """`k_p1_rings<T, SLOTS, MASS, CHUNK, Q, DBG[, KMAT[, SRC]]>`: the fused launch of the step is
-    the fp64 instantiation with Q > 0 and SRC = true, the matrix-only one has Q = 0."""
+    the fp64 instantiation with Q > 0, KMAT = true and SRC > 0, the matrix-only one has Q = 0."""
     if kernel + "<double" not in kernel_name:
         return False
     args = template_args(kernel_name)
     q = int(args[4])
     if not with_load:
         return q == 0
-    return q > 0 and len(args) >= 8 and args[7] == "true" and args[6] == "true"
+    return q > 0 and len(args) >= 8 and args[7] in ("true", "1", "2") and args[6] == "true"
 
 
 def committed_profile(n, order, kernel):

@@ -49,16 +49,12 @@ class Basis(AbstractBasis):
             markers = mesh["vertices", "markers"]
             return coords, conn, markers, mesh["cells", "coordinates"]
         if element.polynomial_order == 2:
-            conn6, xy, markers = dofs.p2_dofs_numpy(
-                mesh["vertices", "coordinates"].cpu().numpy(),
-                mesh["cells", "vertices"].cpu().numpy(),
-                mesh["edges", "vertices"].cpu().numpy(),
-                mesh["edges", "markers"].cpu().numpy(),
-                mesh["vertices", "markers"].cpu().numpy(),
+            # vertex DoFs, then one DoF per edge (dofs.py): sort + binary search on the mesh's device
+            conn, coords, markers = dofs.p2_dofs_torch(
+                mesh["vertices", "coordinates"], mesh["cells", "vertices"], mesh["edges", "vertices"],
+                mesh["edges", "markers"], mesh["vertices", "markers"],
             )
-            coords = torch.tensor(xy, dtype=mesh["vertices", "coordinates"].dtype)
-            conn = torch.tensor(conn6, dtype=torch.int32)
-            return coords, conn, torch.tensor(markers, dtype=torch.int32), coords[conn]
+            return coords, conn, markers, coords[conn.long()]
         raise NotImplementedError("Polynomial order not implemented")
 
     def _compute_basis_parameters(self, coords4global_dofs, global_dofs4elements, nodes4boundary_dofs):

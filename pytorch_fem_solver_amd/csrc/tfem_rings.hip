@@ -87,8 +87,8 @@ static void *pick_ring_mass(bool kmat, bool mass, int nq) {
 // nq = 0: matrix only; kmat = false: the load vector alone; src: source program in the launch
 // (those instantiations live in tfem_rings_src.hip)
 template <typename T>
-static void *pick_ring_kernel(int slots, bool mass, bool chunk, int nq, bool src, bool kmat) {
-  if (src) return pick_ring_src_kernel<T>(slots, mass, chunk, nq, kmat);
+static void *pick_ring_kernel(int slots, bool mass, bool chunk, int nq, bool src, bool kmat, bool wide) {
+  if (src) return pick_ring_src_kernel<T>(slots, mass, chunk, nq, kmat, wide);
   if (slots == 7)
     return chunk ? pick_ring_mass<T, 7, true>(kmat, mass, nq) : pick_ring_mass<T, 7, false>(kmat, mass, nq);
   return chunk ? pick_ring_mass<T, 15, true>(kmat, mass, nq) : pick_ring_mass<T, 15, false>(kmat, mass, nq);
@@ -180,7 +180,10 @@ static int launch_rings(const RingLaunch &L) {
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
-  void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0, src, kmat);
+  // programs that never hold more than two values: three elements per pass of the interpreter
+  bool wide = src && src_depth(L.source) <= 2;
+  if (const char *v = std::getenv("TFEM_SRC_WIDE")) wide = wide && std::atoi(v) != 0;  // developer switch
+  void *kernel = pick_ring_kernel<T>(slots, mass, chunk, load ? tables.nq : 0, src, kmat, wide);
   if (!kernel) return fail(TFEM_ERR_UNSUPPORTED, "Integration order not implemented");
   if constexpr (sizeof(T) == 8) {  // the ablation build exists for fp64 stiffness, 7 slots
     if (kmat && !src && L.flags > 0 && slots == 7 && !mass && (!load || tables.nq == 4)) {

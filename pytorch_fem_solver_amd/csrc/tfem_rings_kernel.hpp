@@ -389,13 +389,14 @@ __device__ __forceinline__ void ring_load_fq(ring_rsrc_t r, unsigned byte, T (&v
 // and staged in LDS; a row reads one of them per fan slot by the slot's
 // 12-bit code (tile-local element | loc << 10).  (Gathering the Q values per row and slot
 // instead is bound by the texture addresser: 14 scattered loads per row.)
-// SRC: the source values are not read from memory but computed in the launch from the program
+// SRC (1: any program, one element per pass of the interpreter; 2: programs that hold at most two
+// values, three elements per pass): the source values are not read from memory but computed in the launch from the program
 // in RingArgs::src: per tile element the three tile-local vertex ids arrive with the plan
 // (tile_tverts, 4 bytes instead of 8 Q), the integration points are formed from the
 // coordinates the tile holds in LDS anyway, f is evaluated there (tfem_source.hpp) and reduced
 // to g[T][.] as above.  That happens at the START of the tile's iteration (its coordinates are
 // complete after the previous iteration's barrier), behind the issue of the next tile's loads.
-template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true, bool SRC = false>
+template <typename T, int SLOTS, bool MASS, bool CHUNK, int QL, bool DBG, bool KMAT = true, int SRC = 0>
 // The matrix-only 15-slot instantiations are asked for 3 waves per SIMD: left alone, hipcc's
 // scheduler hoists every LDS read of the unrolled fan loop and ends at 250 VGPRs (2 waves); with
 // the bound it needs 112-128 and nothing spills (the load-vector instantiations would spill).
@@ -541,7 +542,33 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   // tile's coordinates in LDS (basis.py:90-91: x_q = bar(q)^T X), added to the accumulators of
   // the elements' vertices in LDS (element form: no slot codes, nothing per fan slot)
   auto compute_g = [&](const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1], const T *xyc, T *dst) {
-    if constexpr (SRC) {
+    if constexpr (SRC == 2) {
+      if (wave * 64 >= d.n_elem) return;  // wave-uniform: nothing for this wave in any round
+      unsigned codes[kRingElemPerLane];
+#pragma unroll
+      for (int j = 0; j < kRingElemPerLane; ++j) codes[j] = tv[SRC ? j : 0];
+      T fv[kRingElemPerLane * (QL > 0 ? QL : 1)];
+      src_run_wide<T, (QL > 0 ? QL : 1), kRingElemPerLane>(prog, xyc, codes, a.lam, fv);
+#pragma unroll
+      for (int j = 0; j < kRingElemPerLane; ++j) {
+        const int l = tid + j * kRingBlock;
+        if (l < d.n_elem) {
+          const unsigned code = codes[j];
+          T x0, y0, x1, y1, x2, y2;
+          lds_xy(xyc, code & 0x3FFu, x0, y0);
+          lds_xy(xyc, (code >> 10) & 0x3FFu, x1, y1);
+          lds_xy(xyc, (code >> 20) & 0x3FFu, x2, y2);
+          const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            T g = T(0);
+#pragma unroll
+            for (int q = 0; q < QL; ++q) g = g + fv[j * (QL > 0 ? QL : 1) + q] * a.lamw[i][q];
+            atomicAdd(dst + ((code >> (10 * i)) & 0x3FFu), det * g);
+          }
+        }
+      }
+    } else if constexpr (SRC == 1) {
       // the loop is not unrolled (one copy of the interpreter): every pass takes entry 0 and
       // rotates the array -- a register array indexed by the loop counter would go to scratch
       unsigned codes[kRingElemPerLane];
@@ -802,7 +829,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
 }
 
 // SRC instantiations (tfem_rings_src.hip): nq > 0; kmat = false: the load vector alone.
+// wide: the three-elements-per-pass interpreter (programs of depth <= 2)
 template <typename T>
-void *pick_ring_src_kernel(int slots, bool mass, bool chunk, int nq, bool kmat);
+void *pick_ring_src_kernel(int slots, bool mass, bool chunk, int nq, bool kmat, bool wide);
 
 }  // namespace tfem

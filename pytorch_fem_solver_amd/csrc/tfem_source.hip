@@ -42,6 +42,20 @@ int src_validate(const tfem_source_program *in) {
   return TFEM_OK;
 }
 
+int src_depth(const tfem_source_program *in) {
+  if (!in || in->n_ops < 1 || in->n_ops > kSrcMaxOps) return 0;
+  int depth = 0, peak = 0;
+  for (int i = 0; i < in->n_ops; ++i) {
+    const int op = in->ops[i];
+    if (op >= TFEM_SRC_PUSH_X && op <= TFEM_SRC_PUSH_C)
+      ++depth;
+    else if (op >= TFEM_SRC_ADD && op <= TFEM_SRC_DIV_R)
+      --depth;
+    peak = depth > peak ? depth : peak;
+  }
+  return peak;
+}
+
 template <typename T>
 int src_convert(const tfem_source_program *in, SrcProgram<T> *out) {
   const int st = src_validate(in);

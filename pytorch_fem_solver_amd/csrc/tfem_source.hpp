@@ -36,6 +36,8 @@ struct SrcProgram {
 template <typename T>
 int src_convert(const tfem_source_program *in, SrcProgram<T> *out);
 int src_validate(const tfem_source_program *in);
+// Most values a valid program holds at any time (1 .. TFEM_SOURCE_STACK); 0 for an invalid one.
+int src_depth(const tfem_source_program *in);
 
 #if defined(__HIPCC__)
 
@@ -95,6 +97,13 @@ __device__ __forceinline__ double src_cos_fast(double x) {
     const T t0 = fn(v[0]);                              \
     _Pragma("unroll") for (int q = 0; q + 1 < QL; ++q) v[q] = v[q + 1]; \
     v[QL - 1] = t0;                                     \
+  }
+
+#define TFEM_SRC_WIDE_APPLY(v, fn)                     \
+  _Pragma("unroll 1") for (int it = 0; it < N; ++it) { \
+    const T t0 = fn(v[0]);                             \
+    _Pragma("unroll") for (int i = 0; i + 1 < N; ++i) v[i] = v[i + 1]; \
+    v[N - 1] = t0;                                     \
   }
 
 template <typename T, int QL>
@@ -269,6 +278,102 @@ __device__ __forceinline__ void src_run(const SrcLanes<T> &prog, const T (&x)[QL
 #undef TFEM_SRC_SET
 #pragma unroll
   for (int q = 0; q < QL; ++q) out[q] = s0[q];
+}
+
+// The same for NE elements at once, for programs that never hold more than TWO values (host:
+// src_depth): every stack entry holds the NE * QL values of NE elements, so the program is
+// decoded once per NE elements -- the decode (three v_readlane, a compare tree, the stack
+// moves) costs about as much as four fp64 additions on QL = 4 values, and with one element per
+// pass it was 40 % of the time of a sin * sin source.  Two entries of 12 doubles take the
+// registers four entries of 4 plus the points took; the coordinates of the elements' vertices
+// are read from LDS (`xyc`, tile-local ids in `codes`) when a PUSH needs them, not kept.
+template <typename T, int QL, int NE>
+__device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *xyc, const unsigned (&codes)[NE],
+                                             const T (&lam)[3][kMaxQuad], T (&out)[NE * QL]) {
+  constexpr int N = NE * QL;
+  T s0[N], s1[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) s0[i] = s1[i] = T(0);
+  const int n = prog.n_ops;
+#define TFEM_SRC_SET(expr)             \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) { \
+    const T t = s0[i];                 \
+    const T l = s1[i];                 \
+    (void)t;                           \
+    (void)l;                           \
+    s0[i] = (expr);                    \
+  }
+#pragma unroll 1
+  for (int pc = 0; pc < n; ++pc) {
+    const uint32_t op = uint32_t(__builtin_amdgcn_readlane(int(prog.op), pc));
+    const T c = src_lane_const<T>(prog, pc);
+    if (op <= TFEM_SRC_PUSH_C) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) s1[i] = s0[i];
+    }
+    switch (op) {
+      case TFEM_SRC_PUSH_X:
+      case TFEM_SRC_PUSH_Y: {
+        const int comp = op == TFEM_SRC_PUSH_Y ? 1 : 0;  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const T v0 = xyc[2 * (codes[e] & 0x3FFu) + comp];
+          const T v1 = xyc[2 * ((codes[e] >> 10) & 0x3FFu) + comp];
+          const T v2 = xyc[2 * ((codes[e] >> 20) & 0x3FFu) + comp];
+#pragma unroll
+          for (int q = 0; q < QL; ++q) s0[e * QL + q] = c * ((lam[0][q] * v0 + lam[1][q] * v1) + lam[2][q] * v2);
+        }
+        break;
+      }
+      case TFEM_SRC_PUSH_C: TFEM_SRC_SET(c) break;
+      case TFEM_SRC_ADD: TFEM_SRC_SET(l + t) break;
+      case TFEM_SRC_SUB: TFEM_SRC_SET(l - t) break;
+      case TFEM_SRC_SUB_R: TFEM_SRC_SET(t - l) break;
+      case TFEM_SRC_MUL: TFEM_SRC_SET(l * t) break;
+      case TFEM_SRC_DIV: TFEM_SRC_SET(l / t) break;
+      case TFEM_SRC_DIV_R: TFEM_SRC_SET(t / l) break;
+      case TFEM_SRC_ADD_C: TFEM_SRC_SET(t + c) break;
+      case TFEM_SRC_MUL_C: TFEM_SRC_SET(t * c) break;
+      case TFEM_SRC_RSUB_C: TFEM_SRC_SET(c - t) break;
+      case TFEM_SRC_RDIV_C: TFEM_SRC_SET(c / t) break;
+      case TFEM_SRC_NEG: TFEM_SRC_SET(-t) break;
+      case TFEM_SRC_ABS:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(__builtin_fabs(t)) } else { TFEM_SRC_SET(__builtin_fabsf(t)) }
+        break;
+      case TFEM_SRC_POW_I: {
+        const int e = int(c);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const T t = s0[i];
+          T r = t * t;
+          for (int k = 2; k < e; ++k) r = r * t;
+          s0[i] = r;
+        }
+        break;
+      }
+      case TFEM_SRC_SIN: src_sin<T, N>(s0); TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_COS: src_cos<T, N>(s0); TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_EXP:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_WIDE_APPLY(s0, exp) } else { TFEM_SRC_WIDE_APPLY(s0, expf) }
+        TFEM_SRC_SET(c * t)
+        break;
+      case TFEM_SRC_SQRT:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(c * sqrt(t)) } else { TFEM_SRC_SET(c * sqrtf(t)) }
+        break;
+      case TFEM_SRC_LOG:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_WIDE_APPLY(s0, log) } else { TFEM_SRC_WIDE_APPLY(s0, logf) }
+        TFEM_SRC_SET(c * t)
+        break;
+      case TFEM_SRC_TANH:
+        if constexpr (sizeof(T) == 8) { TFEM_SRC_WIDE_APPLY(s0, tanh) } else { TFEM_SRC_WIDE_APPLY(s0, tanhf) }
+        TFEM_SRC_SET(c * t)
+        break;
+      default: break;
+    }
+  }
+#undef TFEM_SRC_SET
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = s0[i];
 }
 
 #endif  // __HIPCC__

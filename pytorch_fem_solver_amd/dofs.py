@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["p2_dofs_numpy", "edge_ids_for_cells"]
+__all__ = ["p2_dofs_numpy", "p2_dofs_torch", "edge_ids_for_cells"]
 
 
 def edge_ids_for_cells(triangles: np.ndarray, edges: np.ndarray) -> np.ndarray:
@@ -46,4 +46,30 @@ def p2_dofs_numpy(vertices, triangles, edges, edge_markers, vertex_markers):
     markers = np.concatenate(
         [np.asarray(vertex_markers).reshape(-1, 1), np.asarray(edge_markers).reshape(-1, 1)]
     ).astype(np.int32)
+    return conn6, coords, markers
+
+
+def p2_dofs_torch(vertices, triangles, edges, edge_markers, vertex_markers):
+    """The same numbering with torch operations on the tensors' own device (sort + binary
+    search on the GPU for a device-resident mesh: the P2 numbering of a 1e6-element mesh takes
+    milliseconds instead of the seconds of the numpy path).  Returns (conn6 int32 (N_T,6), dof
+    coordinates (N_v+N_e,2), markers int32 (N_v+N_e,1)) on that device."""
+    import torch
+
+    tri = triangles.long()
+    e = torch.sort(edges.long(), dim=1)[0]
+    nv = vertices.shape[0]
+    keys = e[:, 0] * nv + e[:, 1]
+    sorted_keys, order = torch.sort(keys, stable=True)
+    local = torch.stack([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], dim=1)
+    local = torch.sort(local, dim=2)[0]
+    want = (local[..., 0] * nv + local[..., 1]).contiguous()
+    pos = torch.searchsorted(sorted_keys, want).clamp_(0, max(sorted_keys.shape[0] - 1, 0))
+    if not torch.equal(sorted_keys[pos], want):
+        raise ValueError("mesh 'edges' does not contain every edge of every triangle")
+    eid = order[pos]
+    conn6 = torch.cat([tri, eid + nv], dim=1).to(torch.int32)
+    mid = vertices[edges.long()].mean(dim=1)
+    coords = torch.cat([vertices, mid], dim=0)
+    markers = torch.cat([vertex_markers.reshape(-1, 1), edge_markers.reshape(-1, 1)]).to(torch.int32)
     return conn6, coords, markers
