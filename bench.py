@@ -265,6 +265,28 @@ def delaunay_configs(n_points, order):
         }
         del basis, eng, vals
         torch.cuda.empty_cache()
+    # config 3 on the unstructured mesh: P2 on the Morton-renumbered Delaunay triangulation
+    # (vertices with 8 .. 15 neighbours go through k_p2_long_rows)
+    mesh_np = meshes["D_morton"]
+    basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(2, 2))
+    eng = basis._engine
+    vals = eng.bilinear(1.0, 0.0)
+    for _ in range(10):
+        eng.bilinear(1.0, 0.0)
+    torch.cuda.synchronize()
+    ms = event_ms(lambda: eng.bilinear(1.0, 0.0), 10)
+    ne, nv, nnz = eng.n_elems, eng.coords_per_mesh, int(vals.shape[0])
+    algo = 24 * ne + 16 * nv + 8 * nnz
+    plan = eng.p2_plan()
+    out[f"D_morton_P2_{ne / 1e6:.1f}M"] = {
+        "workload": f"P2 stiffness K (CSR), order 2, Delaunay mesh of {nv} points, {ne} elements, {eng.n_dofs} DoFs, nnz {nnz}",
+        "kernel": eng.kernel_name(),
+        "long_vertex_rows": None if plan is None else int(plan["layout"][18]),
+        "kernel_ms": ms,
+        "value": ne / ms / 1e3,
+        "unit": "Melements/s",
+        "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
     return out
 
 

@@ -434,14 +434,16 @@ int tfem_p1_residual_backward(const void *coords, int real_bytes, const void *co
  * row of a vertex DoF or of an edge DoF, no atomics).  Same operation as
  * tfem_tri_bilinear_csr with poly_order = 2 (abstract_basis.py:74-93, element_tri.py:43-70);
  * requires DoFs numbered "vertices, then edges" with the local edge order (v0,v1), (v1,v2),
- * (v2,v0) (conn_dof (n_elems, 6), vertex DoF id = vertex id), at most 7 neighbours per
+ * (v2,v0) (conn_dof (n_elems, 6), vertex DoF id = vertex id), at most 15 neighbours per
  * vertex and a numbering with locality; otherwise create returns TFEM_ERR_UNSUPPORTED and
- * the caller uses the local-block + gather path.
+ * the caller uses the local-block + gather path.  Vertex rows with 8 .. 15 neighbours (every
+ * Delaunay mesh has them) are written by a third launch, one lane per such row.
  *   sizes : layout[24]: [0] vertex-row tiles [1] edge-row tiles [2] n_verts [3] n_edges
  *           [4] max local vertices of a vertex tile [5] of an edge tile [6] max halo of a
  *           vertex tile [7],[8] local vertices listed for vertex / edge tiles
  *           [10..15] byte offsets of desc, rows, vert_gid of the vertex tiles and of the edge
- *           tiles in the packed plan [16] bytes of the packed plan
+ *           tiles in the packed plan [16] bytes of the packed plan [17] byte offset and [18] number
+ *           of the long vertex rows (32-dword records)
  *   pack  : record and descriptor layout: csrc/tfem_p2rows_host.cpp
  * ------------------------------------------------------------------------- */
 int tfem_p2_plan_create(const int32_t *conn_dof_host, int64_t n_elems, int64_t n_verts,
@@ -450,7 +452,8 @@ int tfem_p2_plan_create(const int32_t *conn_dof_host, int64_t n_elems, int64_t n
 int tfem_p2_plan_sizes(const void *plan, int64_t layout[24]);
 int tfem_p2_plan_pack(const void *plan, void *blob_host);
 void tfem_p2_plan_destroy(void *plan);
-/* vals (nnz): every entry written exactly once (two launches: vertex rows, edge rows). */
+/* vals (nnz): every entry written exactly once (launches: vertex rows, long vertex rows if
+ * any, edge rows). */
 int tfem_p2_assemble_rows(const void *coords, int real_bytes, int quad_order, double alpha,
                           double beta, const void *plan_device, const int64_t *plan_layout_host,
                           void *vals, int64_t nnz, void *stream);

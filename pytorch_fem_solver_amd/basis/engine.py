@@ -200,8 +200,8 @@ def unpack_ring_plan(blob, layout):
 
 def p2_plan_host(conn_dof, n_verts, n_dofs, coords, rowptr, colind):
     """Build the P2 row plan on the host (tfem_p2_plan_*).  Raises NotImplementedError when
-    the mesh does not fit it (DoF layout, vertices with more than 7 neighbours, numbering
-    without locality)."""
+    the mesh does not fit it (DoF layout, vertices with more than 15 neighbours, numbering
+    without locality).  Vertices with 8 .. 15 neighbours become long rows (plan["long_rows"])."""
     lib = _native.load()
     conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32)).reshape(-1, 6)
     coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
@@ -231,6 +231,7 @@ def p2_plan_host(conn_dof, n_verts, n_dofs, coords, rowptr, colind):
                    "vert_gid": view(2, np.int32, z[7])},
         "edge": {"desc": view(3, np.int32, 16 * z[1]), "rows": view(4, np.uint32, 4 * z[3]),
                  "vert_gid": view(5, np.int32, z[8])},
+        "long_rows": np.frombuffer(blob, dtype=np.uint32, count=32 * z[18], offset=z[17]),
     }
 
 

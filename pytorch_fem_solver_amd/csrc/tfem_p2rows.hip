@@ -100,6 +100,36 @@ __device__ __forceinline__ void p2_store(const T *stage, int total, int delta, r
   }
 }
 
+// The same when some rows of the wave are LONG rows (written by k_p2_long_rows): their entries
+// are not in the stage, so the CSR position of the rows behind them is further on.  `pre` =
+// stage index of the lane's row, `csr` = CSR offset of the lane's row, `is_long` marks the
+// holes: the stage is streamed out piece by piece between them.
+template <typename T>
+__device__ __forceinline__ void p2_store_pieces(const T *stage, int total, int pre, int csr, bool is_long,
+                                                ring_rsrc_t r_vals) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long holes = __ballot(is_long);
+  int first_lane = 0;  // first lane of the current piece
+  for (;;) {
+    const int stop_lane = holes ? __builtin_ctzll(holes) : 64;  // the piece: lanes [first_lane, stop_lane)
+    if (first_lane < 64 && first_lane < stop_lane) {
+      const int b = __builtin_amdgcn_readlane(pre, first_lane);
+      const int e = stop_lane < 64 ? __builtin_amdgcn_readlane(pre, stop_lane) : total;
+      const int delta = __builtin_amdgcn_readlane(csr, first_lane) - b;
+      for (int s0 = b + lane; s0 < e; s0 += 64) {
+        const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
+        if constexpr (sizeof(T) == 8)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, stage[s0]), r_vals, byte, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, stage[s0]), r_vals, byte, 0, 0);
+      }
+    }
+    if (!holes) break;
+    holes &= holes - 1;
+    first_lane = stop_lane + 1;
+  }
+}
+
 // KIND 0: vertex rows, KIND 1: edge rows
 template <typename T, int KIND, bool MASS>
 __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
@@ -224,6 +254,11 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
     len = k > 0 ? 1 + 2 * k + n_tri : 0;
     const int incl = wave_inclusive_scan(len);
     pre = incl - len;
+    // long rows (8 .. 15 neighbours, written by k_p2_long_rows): k = 0 here, their length only
+    // moves the CSR position of the rows behind them
+    const bool is_long = has_row && k == 0 && (w[3] >> 31) != 0u;
+    const int true_len = is_long ? int(w[3] & 0x7FFFFFFFu) : len;
+    const bool any_long = __ballot(is_long) != 0ull;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       my_stage[i < k ? pre + field(i) : kSpare] = vcol[i];
@@ -233,7 +268,12 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
     my_stage[k > 0 ? pre + int(w[2] >> 27) : kSpare] = diag;
     const int total = __builtin_amdgcn_readlane(incl, 63);
     __builtin_amdgcn_wave_barrier();
-    p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+    if (!any_long) {
+      p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+    } else {
+      const int csr = rs0 + wave_inclusive_scan(true_len) - true_len;
+      p2_store_pieces<T>(my_stage, total, pre, csr, is_long, r_vals);
+    }
   } else {
     // ---- edge row: one or two triangles, each in its own stored frame ------------------------
     const bool has2 = (w[1] >> 10) & 1u;
@@ -275,6 +315,67 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
     __builtin_amdgcn_wave_barrier();
     p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
   }
+}
+
+// Vertex rows with 8 .. 15 neighbours: one lane per row, everything by global ids (the rows are
+// scattered over the mesh: ~10 % of the vertices of a Delaunay mesh).  The walk around the fan is
+// the one of the tile kernel; an entry is written as soon as both triangles that touch its
+// column have been seen, only slot 0 waits for the triangle that closes the fan.
+template <typename T, bool MASS>
+__global__ __launch_bounds__(kP2Block) void k_p2_long_rows(const P2RowArgs<T> a, unsigned off_long, int n_long) {
+  const int row = int(blockIdx.x) * kP2Block + int(threadIdx.x);
+  if (row >= n_long) return;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(a.plan + off_long) + 32 * size_t(row);
+  const uint32_t v = rec[0];
+  T *out = a.vals + rec[1];
+  const int k = int(rec[2] & 0xFFu);
+  const int dpos = int(rec[2] >> 8);
+  const uint32_t flags = rec[3];
+  auto field = [&](int f) { return int((rec[19 + f / 5] >> (6 * (f % 5))) & 63u); };
+  const T xv = a.coords[2 * size_t(v)], yv = a.coords[2 * size_t(v) + 1];
+  uint32_t g = rec[4];
+  T ecx = a.coords[2 * size_t(g)] - xv, ecy = a.coords[2 * size_t(g) + 1] - yv;
+  T qc = ecx * ecx + ecy * ecy;
+  const T e0x = ecx, e0y = ecy, q0 = qc;
+  T diag = T(0), v0 = T(0), ev0 = T(0);   // slot 0's two entries: complete when the fan closes
+  T vcarry = T(0), ecarry = T(0);         // what slot i - 1's triangle added to slot i
+  for (int i = 0; i < k; ++i) {
+    const bool wraps = i + 1 == k;
+    T enx, eny, qn;
+    if (wraps) {
+      enx = e0x, eny = e0y, qn = q0;
+    } else {
+      g = rec[5 + i];
+      enx = a.coords[2 * size_t(g)] - xv;
+      eny = a.coords[2 * size_t(g) + 1] - yv;
+      qn = enx * enx + eny * eny;
+    }
+    const T p = ecx * enx + ecy * eny;
+    const T cross = ecx * eny - ecy * enx;
+    const uint32_t flag = (flags >> (2 * i)) & 3u;
+    T r[6];
+    p2_block_row<T, MASS>(a, qc, qn, p, cross, flag, r);
+    const bool fwd = flag != 2u;
+    diag = diag + r[0];
+    const T vi = vcarry + (fwd ? r[1] : r[2]), ei = ecarry + (fwd ? r[3] : r[5]);
+    vcarry = fwd ? r[2] : r[1];
+    ecarry = fwd ? r[5] : r[3];
+    if (i == 0) {
+      v0 = vi;
+      ev0 = ei;
+    } else {
+      out[field(i)] = vi;
+      out[field(15 + i)] = ei;
+    }
+    if (flag) out[field(30 + i)] = r[4];
+    ecx = enx;
+    ecy = eny;
+    qc = qn;
+  }
+  // the closing triangle's share of slot 0 (zero for an open fan: its last slot has no triangle)
+  out[field(0)] = v0 + vcarry;
+  out[field(15)] = ev0 + ecarry;
+  out[dpos] = diag;
 }
 
 template <typename T>
@@ -346,6 +447,15 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
     void *params[] = {&a};
     hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, stream);
     if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 row kernel launch: %s", hipGetErrorString(e));
+    if (kind == 0 && z[18] > 0) {  // the vertex rows with 8 .. 15 neighbours
+      const dim3 lgrid{unsigned((z[18] + kP2Block - 1) / kP2Block)};
+      if (mass)
+        hipLaunchKernelGGL((k_p2_long_rows<T, true>), lgrid, block, 0, stream, a, unsigned(z[17]), int(z[18]));
+      else
+        hipLaunchKernelGGL((k_p2_long_rows<T, false>), lgrid, block, 0, stream, a, unsigned(z[17]), int(z[18]));
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 long-row kernel launch: %s", hipGetErrorString(e));
+    }
   }
   return TFEM_OK;
 }

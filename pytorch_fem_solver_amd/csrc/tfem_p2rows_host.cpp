@@ -11,7 +11,10 @@
 //     (a, b, c) / (a2, b2, d); columns a, b, c, d, itself and the four other edges: 6 or 9.
 // Tiles are made of chunks of <= 64 CONSECUTIVE DoFs (one chunk per wave: a wave writes one
 // contiguous piece of the CSR array, its offset is in the descriptor), four chunks per tile.
-// Meshes whose numbering has no locality, vertices with more than 7 neighbours, fans without
+// Vertices with 8 to 15 neighbours (every Delaunay mesh has some) keep their place in the tiles
+// as rows of length zero and are listed as LONG ROWS: 32-dword records with global ids, handled
+// by a launch of their own (one lane per long row, k_p2_long_rows).
+// Meshes whose numbering has no locality, vertices with more than 15 neighbours, fans without
 // ring form and DoF layouts other than "vertices, then edges" are reported as
 // TFEM_ERR_UNSUPPORTED: the caller then assembles element blocks and gathers them
 // (tfem_tri_bilinear_csr in local-block mode + tfem_csr_gather).
@@ -22,6 +25,11 @@
 //   w2[24:27)         : k;  w2[27:32): position of the diagonal
 //   w3..w6            : 21 positions of 5 bits, 6 per dword: field i = column n_i, field 7 + i =
 //                       edge (v, n_i), field 14 + i = opposite edge of slot i's triangle
+//   a LONG row has k = 0 and w3 = 0x80000000 | number of entries of the row (the rows behind it in
+//   the wave start that many entries later in the CSR array)
+// Long-row record (32 dwords): vertex id, CSR offset of the row, k | position of the diagonal << 8,
+//   triangle flags (2 bits per slot), 15 neighbour vertex ids (global), then 45 positions of 6 bits,
+//   5 per dword, from dword 19: field i = column n_i, 15 + i = edge (v, n_i), 30 + i = opposite edge
 // Edge-row record (4 dwords):
 //   w0 : local ids a | b << 10 | c << 20 (frame of triangle 1)
 //   w1 : local id d | has2 << 10 | rev << 11 (triangle 2's frame starts at b: (b, a, d))
@@ -49,6 +57,7 @@ struct P2Plan {
   std::vector<int32_t> desc[2];
   std::vector<uint32_t> rows[2];
   std::vector<int32_t> vert_gid[2];
+  std::vector<uint32_t> long_rows;  // 32 dwords per vertex with 8 .. 15 neighbours
   int32_t max_n_vert[2] = {0, 0}, max_n_halo = 0;
   int64_t n_tiles[2] = {0, 0};
   int64_t n_verts = 0, n_edges = 0;
@@ -56,12 +65,14 @@ struct P2Plan {
 
 namespace {
 
+constexpr int kP2FanMax = 15;  // neighbours of a vertex the plan can express (7 in the tile records)
+
 struct P2Fan {
   int k = 0;
-  int32_t nb[8];
-  int flag[8];
-  int32_t edge_v[8];    // DoF of edge (v, n_i)
-  int32_t edge_op[8];   // DoF of the edge opposite to v in slot i's triangle (-1: none)
+  int32_t nb[kP2FanMax + 1];
+  int flag[kP2FanMax + 1];
+  int32_t edge_v[kP2FanMax + 1];    // DoF of edge (v, n_i)
+  int32_t edge_op[kP2FanMax + 1];   // DoF of the edge opposite to v in slot i's triangle (-1: none)
 };
 
 // Fan of vertex v from its incident elements (conn6: three vertices, three edge DoFs).
@@ -70,10 +81,10 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
   const int nt = int(adj_last - adj_first);
   fan.k = 0;
   if (nt == 0) return true;
-  if (nt > 7) return false;
-  int32_t ta[8], tb[8], tea[8], teo[8], teb[8];
-  int32_t nb[9], nb_edge[9];
-  int cnt[9], tri[9][2];
+  if (nt > kP2FanMax) return false;
+  int32_t ta[kP2FanMax + 1], tb[kP2FanMax + 1], tea[kP2FanMax + 1], teo[kP2FanMax + 1], teb[kP2FanMax + 1];
+  int32_t nb[kP2FanMax + 2], nb_edge[kP2FanMax + 2];
+  int cnt[kP2FanMax + 2], tri[kP2FanMax + 2][2];
   int n_nb = 0;
   for (int t = 0; t < nt; ++t) {
     const int32_t *c = conn6 + 6 * int64_t(adj_first[t]);
@@ -96,7 +107,7 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
       int i = 0;
       while (i < n_nb && nb[i] != w) ++i;
       if (i == n_nb) {
-        if (n_nb == 8) return false;
+        if (n_nb == kP2FanMax + 1) return false;
         nb[n_nb] = w;
         nb_edge[n_nb] = ew;
         cnt[n_nb] = 0;
@@ -107,12 +118,12 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
       tri[i][cnt[i]++] = t;
     }
   }
-  if (n_nb > 7) return false;
+  if (n_nb > kP2FanMax) return false;
   for (int t = 0; t < nt; ++t)
     for (int u = t + 1; u < nt; ++u)
       if ((ta[t] == ta[u] && tb[t] == tb[u]) || (ta[t] == tb[u] && tb[t] == ta[u])) return false;
-  bool used[8] = {false};
-  bool seen[9] = {false};
+  bool used[kP2FanMax + 1] = {false};
+  bool seen[kP2FanMax + 2] = {false};
   auto index_of = [&](int32_t w) {
     int i = 0;
     while (nb[i] != w) ++i;
@@ -362,7 +373,7 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
       for (int l = 0; l < n_own; ++l) {
         const int32_t u = owned[size_t(l)];
         if (!build_p2_fan(conn6, u, adj.data() + adj_ptr[size_t(u)], adj.data() + adj_ptr[size_t(u) + 1], fan))
-          return fail(TFEM_ERR_UNSUPPORTED, "vertex %d: more than 7 neighbours or no ring form", u);
+          return fail(TFEM_ERR_UNSUPPORTED, "vertex %d: more than 15 neighbours or no ring form", u);
         int n_tri = 0;
         for (int i = 0; i < fan.k; ++i) n_tri += fan.flag[i] != 0;
         const int len = int(rowptr[u + 1] - rowptr[u]);
@@ -370,6 +381,27 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
           return fail(TFEM_ERR_UNSUPPORTED, "row %d: %d entries for %d neighbours", u, len, fan.k);
         uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool ok = true;
+        if (fan.k > 7) {
+          // a long row: nothing for the tile's lane to do, the row goes to the long-row launch
+          w[3] = 0x80000000u | uint32_t(len);
+          uint32_t r[32] = {0};
+          r[0] = uint32_t(u);
+          r[1] = uint32_t(rowptr[u]);
+          r[2] = uint32_t(fan.k) | pos_in_row(rowptr, colind, u, u, ok) << 8;
+          uint32_t field[45] = {0};
+          for (int i = 0; i < fan.k; ++i) {
+            r[3] |= uint32_t(fan.flag[i]) << (2 * i);
+            r[4 + i] = uint32_t(fan.nb[i]);
+            field[i] = pos_in_row(rowptr, colind, u, fan.nb[i], ok);
+            field[15 + i] = pos_in_row(rowptr, colind, u, fan.edge_v[i], ok);
+            if (fan.flag[i]) field[30 + i] = pos_in_row(rowptr, colind, u, fan.edge_op[i], ok);
+          }
+          for (int f = 0; f < 45; ++f) r[19 + f / 5] |= field[f] << (6 * (f % 5));
+          if (!ok) return fail(TFEM_ERR_INVALID_ARGUMENT, "row %d: a column is missing from the CSR pattern", u);
+          plan.long_rows.insert(plan.long_rows.end(), r, r + 32);
+          plan.rows[0].insert(plan.rows[0].end(), w, w + 8);
+          continue;
+        }
         uint32_t field[21] = {0};
         for (int i = 0; i < fan.k; ++i) {
           w[i / 3] |= uint32_t(local_id[size_t(fan.nb[i])]) << (10 * (i % 3));
@@ -509,15 +541,18 @@ void p2_layout(const P2Plan &p, int64_t layout[kP2LayoutLen]) {
   layout[6] = p.max_n_halo;
   layout[7] = int64_t(p.vert_gid[0].size());
   layout[8] = int64_t(p.vert_gid[1].size());
-  const int64_t bytes[6] = {int64_t(p.desc[0].size()) * 4, int64_t(p.rows[0].size()) * 4,
+  const int64_t bytes[7] = {int64_t(p.desc[0].size()) * 4, int64_t(p.rows[0].size()) * 4,
                             int64_t(p.vert_gid[0].size()) * 4, int64_t(p.desc[1].size()) * 4,
-                            int64_t(p.rows[1].size()) * 4, int64_t(p.vert_gid[1].size()) * 4};
+                            int64_t(p.rows[1].size()) * 4, int64_t(p.vert_gid[1].size()) * 4,
+                            int64_t(p.long_rows.size()) * 4};
+  const int slot_of[7] = {10, 11, 12, 13, 14, 15, 17};
   int64_t off = 0;
-  for (int i = 0; i < 6; ++i) {
-    layout[10 + i] = off;
+  for (int i = 0; i < 7; ++i) {
+    layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
   layout[16] = off + 64;
+  layout[18] = int64_t(p.long_rows.size() / 32);
 }
 
 }  // namespace
@@ -567,6 +602,7 @@ int tfem_p2_plan_pack(const void *plan_handle, void *blob_host) {
   std::memcpy(out + layout[13], p->desc[1].data(), p->desc[1].size() * 4);
   std::memcpy(out + layout[14], p->rows[1].data(), p->rows[1].size() * 4);
   std::memcpy(out + layout[15], p->vert_gid[1].data(), p->vert_gid[1].size() * 4);
+  std::memcpy(out + layout[17], p->long_rows.data(), p->long_rows.size() * 4);
   return TFEM_OK;
 }
 

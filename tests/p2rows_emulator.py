@@ -38,6 +38,7 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
     nnz = int(rowptr[-1])
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
+    long_seen = set()
     # ---- vertex rows
     part = plan["vertex"]
     rows = part["rows"].reshape(-1, 8).astype(np.uint64)
@@ -58,6 +59,12 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
             k = int((w[2] >> np.uint64(24)) & np.uint64(7))
             v = int(gid[r])
             start = int(rowptr[v])
+            if k == 0 and int(w[3] >> np.uint64(31)):
+                # a long row (8 .. 15 neighbours): its length moves the rows behind it, the
+                # entries come from the long-row record below
+                assert rowptr[v + 1] - start == int(w[3] & np.uint64(0x7FFFFFFF))
+                long_seen.add(v)
+                continue
             if k == 0:
                 assert rowptr[v + 1] == start
                 continue
@@ -88,6 +95,40 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
             for pos, value in out.items():
                 vals[start + pos] = value
                 writes[start + pos] += 1
+    # ---- long vertex rows: global ids, as k_p2_long_rows walks them
+    long_rows = plan["long_rows"].reshape(-1, 32).astype(np.uint64)
+    assert {int(r[0]) for r in long_rows} == long_seen and len(long_rows) == len(long_seen)
+    for r in long_rows:
+        v, start = int(r[0]), int(r[1])
+        k, dpos, flagword = int(r[2] & np.uint64(0xFF)), int(r[2] >> np.uint64(8)), int(r[3])
+        assert 8 <= k <= 15 and start == rowptr[v]
+        ids = [int(r[4 + i]) for i in range(k)]
+        flags = [(flagword >> (2 * i)) & 3 for i in range(k)]
+        field = lambda f: int((r[19 + f // 5] >> np.uint64(6 * (f % 5))) & np.uint64(63))  # noqa: E731
+        diag, vcol, ecol = 0.0, np.zeros(k), np.zeros(k)
+        out = {}
+        for i in range(k):
+            nxt = 0 if i + 1 == k else i + 1
+            if flags[i] == 0:
+                continue
+            p1, p2 = (coords[ids[i]], coords[ids[nxt]]) if flags[i] == 1 else (coords[ids[nxt]], coords[ids[i]])
+            rr = _block_row(tab, 0, coords[v], p1, p2, alpha, beta)
+            i1, i2 = (i, nxt) if flags[i] == 1 else (nxt, i)
+            diag += rr[0]
+            vcol[i1] += rr[1]
+            vcol[i2] += rr[2]
+            ecol[i1] += rr[3]
+            ecol[i2] += rr[5]
+            out[field(30 + i)] = rr[4]
+        for i in range(k):
+            out[field(i)] = vcol[i]
+            out[field(15 + i)] = ecol[i]
+        out[dpos] = diag
+        length = 1 + 2 * k + sum(1 for f in flags if f)
+        assert sorted(out) == list(range(length)) and rowptr[v + 1] - start == length
+        for pos, value in out.items():
+            vals[start + pos] = value
+            writes[start + pos] += 1
     # ---- edge rows
     part = plan["edge"]
     rows = part["rows"].reshape(-1, 4).astype(np.uint64)

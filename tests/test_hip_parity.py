@@ -850,15 +850,21 @@ def test_two_pass_gather_equals_atomic_scatter_and_is_reproducible(order):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("form", ["stiffness", "stiffness_mass", "mass"])
 @pytest.mark.parametrize("order", [2, 4])
-def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order):
+@pytest.mark.parametrize("mesh_kind", ["structured", "delaunay_morton"])
+def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order, mesh_kind):
     """k_p2_rows (owner-computes vertex rows and edge rows) on a mesh stored with mixed
     orientation: equal to the oracle's P2 assembly entry by entry and to the element-block +
-    gather path."""
+    gather path.  delaunay_morton: vertices with 8 .. 15 neighbours -> k_p2_long_rows, holes in
+    the tile kernel's output runs."""
     from pytorch_fem_solver_amd import dofs, meshgen
 
     torch.set_default_dtype(dtype)
     tol = TOL if dtype == torch.float64 else 2e-5
-    mesh_np = meshgen.unit_square(70, 0.25, 4)
+    if mesh_kind == "structured":
+        mesh_np = meshgen.unit_square(70, 0.25, 4)
+    else:
+        native = meshgen.delaunay_square(6000, 7)
+        mesh_np = meshgen.permute_mesh(native, vertex_order=meshgen.morton_order(native["vertices"]))
     tri = mesh_np["triangles"].copy()
     flip = np.random.default_rng(5).random(tri.shape[0]) < 0.4
     tri[flip] = tri[flip][:, [0, 2, 1]]
@@ -870,6 +876,9 @@ def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order):
         basis._engine.kernel = kernel
         got[kernel] = basis._engine.bilinear(*ab)
         assert basis._engine.kernel_name() == ("k_p2_rows" if kernel == "rows" else "k_p2_bilinear_atomic")
+        if kernel == "rows":
+            n_long = int(basis._engine.p2_plan()["layout"][18])
+            assert (n_long > 100) == (mesh_kind == "delaunay_morton")
     verts = mesh_np["vertices"] if dtype == torch.float64 else mesh_np["vertices"].astype(np.float32)
     conn6, xy, _ = dofs.p2_dofs_numpy(mesh_np["vertices"], tri, mesh_np["edges"], mesh_np["edge_markers"],
                                       mesh_np["vertex_markers"])
@@ -883,13 +892,26 @@ def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order):
     assert scaled_error(got["rows"].cpu().double(), got["gather"].cpu().double()) <= (1e-13 if dtype == torch.float64 else 2e-5)
 
 
-def test_p2_falls_back_to_gather_when_a_vertex_has_more_than_seven_neighbours():
+def test_p2_row_plan_on_unstructured_meshes_and_its_fallback():
+    """A Delaunay mesh with a numbering that has locality (Morton) runs the row kernels (its
+    vertices with more than seven neighbours as long rows); the native scipy numbering of a
+    larger one has no locality and takes element blocks + gather, as before."""
     from pytorch_fem_solver_amd import meshgen
 
-    basis = tf().Basis(tf().MeshTri(meshgen.delaunay_square(4000, 3)), tf().ElementTri(2, 2))
+    native = meshgen.delaunay_square(8000, 3)
+    basis = tf().Basis(tf().MeshTri(native), tf().ElementTri(2, 2))
     assert basis._engine.p2_plan() is None and basis._engine.kernel_name() == "k_p2_bilinear_atomic"
+    want = basis._engine.bilinear(1.0, 1.0)
+    morton = meshgen.permute_mesh(native, vertex_order=meshgen.morton_order(native["vertices"]))
+    basis = tf().Basis(tf().MeshTri(morton), tf().ElementTri(2, 2))
+    assert basis._engine.kernel_name() == "k_p2_rows" and int(basis._engine.p2_plan()["layout"][18]) > 0
+    got = basis.integrate_bilinear_form(stiffness_mass, layout="csr")
+    # the same operator up to the renumbering: compare invariants (the entry-by-entry check against
+    # the oracle is test_p2_row_kernels_against_oracle_and_gather)
+    assert abs(float(got.values.sum()) - float(want.sum())) <= 1e-9 * float(want.abs().sum())
+    assert abs(float((got.values ** 2).sum()) - float((want ** 2).sum())) <= 1e-9 * float((want ** 2).sum())
     basis = tf().Basis(tf().MeshTri(meshgen.unit_square(30, 0.25, 1)), tf().ElementTri(2, 2))
-    assert basis._engine.kernel_name() == "k_p2_rows"
+    assert basis._engine.kernel_name() == "k_p2_rows" and int(basis._engine.p2_plan()["layout"][18]) == 0
 
 
 def test_csr_spmv_and_cg_solve_against_the_dense_reference_solve():

@@ -292,16 +292,46 @@ def test_p2_row_plan_is_a_valid_exact_cover(kind, form):
     assert scaled_error(vals, want) <= 1e-13
 
 
-def test_p2_row_plan_rejects_what_it_cannot_express():
+def test_p2_row_plan_long_rows_on_delaunay_meshes_and_what_it_rejects():
+    """Vertices with 8 .. 15 neighbours (every Delaunay mesh) become long rows; the walk of the
+    plan -- tile rows, long rows, edge rows -- writes every CSR entry once with the oracle's
+    values.  A numbering without locality and a vertex with 16 neighbours are refused."""
     from pytorch_fem_solver_amd import dofs, meshgen
     from pytorch_fem_solver_amd.basis.engine import p2_plan_host, symbolic_host
 
-    mesh = meshgen.delaunay_square(3000, 2)  # vertices with more than 7 neighbours
+    native = meshgen.delaunay_square(3000, 2)
+    mesh = meshgen.permute_mesh(native, vertex_order=meshgen.morton_order(native["vertices"]))
     conn6, xy, _ = dofs.p2_dofs_numpy(mesh["vertices"], mesh["triangles"], mesh["edges"],
                                       mesh["edge_markers"], mesh["vertex_markers"])
+    nv, nd = mesh["vertices"].shape[0], xy.shape[0]
+    rowptr, colind, slots = symbolic_host(conn6, nd)
+    assert int(np.diff(rowptr[: nv + 1]).max()) > 22  # rows of vertices with more than 7 neighbours
+    try:
+        plan = p2_plan_host(conn6, nv, nd, mesh["vertices"], rowptr, colind)
+    except NotImplementedError as exc:  # the edge numbering of this generator may lack locality
+        assert "locality" in str(exc)
+        plan = None
+    if plan is not None:
+        assert plan["long_rows"].size >= 32
+        for beta in (0.0, 1.0):
+            vals, writes = run_p2_plan(plan, mesh["vertices"], rowptr, nv, 2, 1.0, beta)
+            assert (writes == 1).all()
+            geo = orc.geometry(mesh["vertices"][mesh["triangles"]], 2, 2)
+            integrand = orc.integrand_stiffness_mass(geo) if beta else orc.integrand_stiffness(geo)
+            local = orc.integrate_local(integrand, geo["dx"])
+            want = orc.assemble_csr_values(local, slots.reshape(-1, 6, 6), colind.shape[0])
+            assert scaled_error(vals, want) <= 1e-13
+    # a fan of 16 triangles around one vertex
+    k = 16
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    verts = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], 1)])
+    tris = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)], dtype=np.int32)
+    edges = np.unique(np.sort(np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]]), axis=1), axis=0)
+    conn6, xy, _ = dofs.p2_dofs_numpy(verts, tris, edges.astype(np.int32), np.zeros((edges.shape[0], 1), np.int32),
+                                      np.zeros((k + 1, 1), np.int32))
     rowptr, colind, _ = symbolic_host(conn6, xy.shape[0])
-    with pytest.raises(NotImplementedError):
-        p2_plan_host(conn6, mesh["vertices"].shape[0], xy.shape[0], mesh["vertices"], rowptr, colind)
+    with pytest.raises(NotImplementedError, match="15 neighbours"):
+        p2_plan_host(conn6, k + 1, xy.shape[0], verts, rowptr, colind)
 
 
 @pytest.mark.parametrize("seed", range(10))
