@@ -176,7 +176,7 @@ static int launch_rings(const RingLaunch &L) {
   a.lds_elem = load ? int(z[17]) : 0;
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
                      (kmat ? size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) : 0) +
-                     (src ? size_t(2 * a.lds_vert) * sizeof(T) : load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
+                     (src ? size_t(2 * kRingBlock) * sizeof(T) : load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;

@@ -436,11 +436,12 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
   if (FQ && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
     gtab[3 * a.lds_elem + tid] = T(0);
-  // SRC: the same LDS region holds the load-vector accumulators, one per tile-local vertex,
-  // double-buffered by tile parity (zeroed here; the other buffer again in every phase D)
+  // SRC: the same LDS region holds the load-vector accumulators, one per OWNED row (the sums of
+  // halo vertices would never be read: their shares are not added at all), double-buffered by
+  // tile parity (zeroed here; the other buffer again in every phase D)
   T *faccbuf = gtab;
   if (SRC)
-    for (int i = tid; i < 2 * a.lds_vert; i += kRingBlock) faccbuf[i] = T(0);
+    for (int i = tid; i < 2 * kRingBlock; i += kRingBlock) faccbuf[i] = T(0);
 
   // SRC: the program, one operation per lane, for the whole launch
   SrcLanes<T> prog;
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
             T g = T(0);
 #pragma unroll
             for (int q = 0; q < QL; ++q) g = g + fv[j * (QL > 0 ? QL : 1) + q] * a.lamw[i][q];
-            atomicAdd(dst + ((code >> (10 * i)) & 0x3FFu), det * g);
+            const unsigned lid = (code >> (10 * i)) & 0x3FFu;
+            if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
           }
         }
       }
@@ -602,7 +604,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
             T g = T(0);
 #pragma unroll
             for (int q = 0; q < QL; ++q) g = g + fv[q] * a.lamw[i][q];
-            atomicAdd(dst + ((code >> (10 * i)) & 0x3FFu), det * g);
+            const unsigned lid = (code >> (10 * i)) & 0x3FFu;
+            if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
           }
         }
       }
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     if (SRC) {
       // ---- G ---- source values of tile k (its coordinates are complete).  Before A: the
       // registers of tile k+1's loads are not live while the program runs (3 workgroups per CU)
-      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * a.lds_vert);
+      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * kRingBlock);
       ring_lds_barrier();
     }
     // ---- A ----
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     T facc = T(0);
     if (SRC) {  // the row's sum is complete: one LDS read
       const int my_row = dc.row0 + lane;
-      facc = faccbuf[cur * a.lds_vert + (my_row < dc.row1 ? my_row : 0)];
+      facc = faccbuf[cur * kRingBlock + (my_row < dc.row1 ? my_row : 0)];
     }
     if (FQ) {
       const T *g = gtab;
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     if (SRC) {
       // the accumulators the NEXT tile adds to (the other buffer): the rows of the previous tile
       // read them before the last barrier E, the next tile's G starts behind the coming one
-      for (int i = tid; i < a.lds_vert; i += kRingBlock) faccbuf[(cur ^ 1) * a.lds_vert + i] = T(0);
+      faccbuf[(cur ^ 1) * kRingBlock + tid] = T(0);
     }
     if (t_n >= 0) {
       park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
