@@ -312,7 +312,9 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *            tile_tverts (uint32 per tile element, in the order of the tile's ascending element
  *            list: the three tile-local vertex ids of the element in its own local order,
  *            10 bits each; desc[19] of a tile = its offset into this array), 0 when absent
- *            [21] entries of tile_tverts [22..23] reserved
+ *            [21] entries of tile_tverts [22] byte offset and [23] number of the long rows (24-dword
+ *            records of the vertices with 8 .. 15 neighbours in a plan with 4-dword records: their
+ *            rows are written by a second launch; csrc/tfem_rings_host.cpp)
  *   pack   : desc int32 (20 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
  *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
  *            wave 0..3, CSR offset of the first row of wave 0..3, offset into tile_elems,

@@ -194,6 +194,7 @@ def unpack_ring_plan(blob, layout):
         "row_ecodes": np.frombuffer(blob, dtype=np.uint32, count=((12 * z[6] + 31) // 32) * z[1], offset=z[15]),
         "tile_elems": np.frombuffer(blob, dtype=np.int32, count=z[19], offset=z[16]),
         "tile_tverts": np.frombuffer(blob, dtype=np.uint32, count=z[21], offset=z[20]),
+        "long_rows": np.frombuffer(blob, dtype=np.uint32, count=24 * z[23], offset=z[22]),
         "elems_staged": bool(z[18]),
     }
 
@@ -559,6 +560,9 @@ class AssemblyEngine:
                         "chunked": plan["chunked"],
                         "elems_staged": plan["elems_staged"],
                         "has_tverts": int(plan["layout"][21]) > 0 or int(plan["layout"][19]) == 0,
+                        # long rows: their load-vector entries come from the element-form
+                        # accumulation of the source-program launch only
+                        "fq_ok": bool(plan["elems_staged"]) and int(plan["layout"][23]) == 0,
                         "rows_per_run": plan["rowstart"].size / n_runs,
                     }
             if self._rings is False and self.kernel == "rings":
@@ -913,7 +917,7 @@ class AssemblyEngine:
             if self._rings_take_source():
                 return self._assemble_rings(alpha, beta, out=out or (None, None), source=source)
             fq = self.source_values(source)
-        if self._use_rings() and self.ring_plan()["elems_staged"]:
+        if self._use_rings() and self.ring_plan()["fq_ok"]:
             return self._assemble_rings(alpha, beta, fq, out=out or (None, None))
         if self.tile_plan() is not None:
             vals, f = self._assemble_tiles(alpha, beta, want_matrix=True, fq=fq)
@@ -929,7 +933,7 @@ class AssemblyEngine:
         """(N_dof,) vector of sum_q f_q phi_i dx_q; fq is (E, Q) on any device."""
         # the vector alone: row form with the source values staged per tile (142 us at 1e7
         # elements) when the ring plan applies, the element-form tile kernel (149 us) otherwise
-        if self.kernel != "tiles" and self._use_rings() and self.ring_plan()["elems_staged"]:
+        if self.kernel != "tiles" and self._use_rings() and self.ring_plan()["fq_ok"]:
             return self._assemble_rings(0.0, 0.0, fq, want_matrix=False)
         if self.tile_plan() is not None:
             return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]

@@ -23,6 +23,66 @@
 
 namespace tfem {
 
+// Rows of vertices with 8 .. 15 neighbours in a plan with long rows (tfem_rings_host.cpp): one
+// lane per row, coordinates by global ids.  The walk around the fan is ring_row's; an entry is
+// written as soon as both triangles that touch its column have been seen, only slot 0 waits for the
+// triangle that closes the fan.  ~10 % of the vertices of a Delaunay mesh.
+template <typename T, bool MASS>
+__global__ __launch_bounds__(kRingBlock) void k_p1_long_rows(const T *coords, const unsigned char *plan,
+                                                             unsigned off_long, int n_long, T *vals, T stiff_w,
+                                                             T mass_d, T mass_o) {
+  const int row = int(blockIdx.x) * kRingBlock + int(threadIdx.x);
+  if (row >= n_long) return;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(plan + off_long) + 24 * size_t(row);
+  const uint32_t v = rec[0];
+  T *out = vals + rec[1];
+  const int k = int(rec[2] & 0xFFu);
+  const int dpos = int(rec[2] >> 8);
+  const uint32_t flags = rec[3];
+  auto pos = [&](int i) { return int((rec[19 + i / 8] >> (4 * (i % 8))) & 15u); };
+  const T xv = coords[2 * size_t(v)], yv = coords[2 * size_t(v) + 1];
+  uint32_t g = rec[4];
+  T ecx = coords[2 * size_t(g)] - xv, ecy = coords[2 * size_t(g) + 1] - yv;
+  T qc = ecx * ecx + ecy * ecy;
+  const T e0x = ecx, e0y = ecy, q0 = qc;
+  T sum = T(0), dsum = T(0), first = T(0), carry = T(0);
+  for (int i = 0; i < k; ++i) {
+    T enx, eny, qn;
+    if (i + 1 == k) {
+      enx = e0x, eny = e0y, qn = q0;
+    } else {
+      g = rec[5 + i];
+      enx = coords[2 * size_t(g)] - xv;
+      eny = coords[2 * size_t(g) + 1] - yv;
+      qn = enx * enx + eny * eny;
+    }
+    const T p = ecx * enx + ecy * eny;
+    const T cross = ecx * eny - ecy * enx;
+    const uint32_t flag = (flags >> (2 * i)) & 3u;
+    const T cs = flag_weight<T>(stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
+    T here = cs * (p - qn), next = cs * (p - qc);  // to column n_i, to column n_next
+    if (MASS) {
+      const T sdet = flag_weight<T>(T(1), flag) * cross;
+      here = here + mass_o * sdet;
+      next = next + mass_o * sdet;
+      dsum = dsum + sdet;
+    }
+    const T entry = carry + here;
+    sum = sum + here + next;
+    carry = next;
+    if (i == 0)
+      first = entry;
+    else
+      out[pos(i)] = entry;
+    ecx = enx;
+    ecy = eny;
+    qc = qn;
+  }
+  out[pos(0)] = first + carry;  // the closing triangle's share (zero for an open fan)
+  // stiffness rows sum to zero; the mass part is taken out of the sum and added on the diagonal
+  out[dpos] = MASS ? mass_d * dsum - (sum - T(2) * mass_o * dsum) : -sum;
+}
+
 struct RingLaunch {
   const void *coords;
   int quad_order;
@@ -108,7 +168,7 @@ static int launch_rings(const RingLaunch &L) {
   if (!kmat && !load) return fail(TFEM_ERR_INVALID_ARGUMENT, "nothing to assemble");
   if (!L.coords || !L.plan || (load && !L.fout)) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (z[0] < 0 || z[4] > kRingBlock || z[3] > kRingVertCap || z[4] > z[3] || z[14] > kRingHaloCap ||
-      !((z[6] == 7 && z[7] == 4) || (z[6] == 15 && z[7] == 8)) || z[5] > z[6] + 1)
+      !((z[6] == 7 && z[7] == 4) || (z[6] == 15 && z[7] == 8)) || (z[5] > z[6] + 1 && z[23] == 0) || z[5] > 16)
     return fail(TFEM_ERR_INVALID_ARGUMENT, "ring plan exceeds the kernel's capacities");
   RingArgs<T> a;
   std::memset(&a, 0, sizeof(a));
@@ -138,6 +198,9 @@ static int launch_rings(const RingLaunch &L) {
   a.xcd_interleave = load ? 4 : 0;
   if (const char *v = std::getenv("TFEM_RINGS_XCD"))  // developer switch: block size, 0 = ranges
     a.xcd_interleave = std::strcmp(v, "interleave") == 0 ? 1 : std::atoi(v);
+  if (load && !src && z[23] > 0)
+    return fail(TFEM_ERR_UNSUPPORTED, "a ring plan with long rows takes the load vector of a source program, "
+                "not of pre-evaluated source values");
   if (load && (z[18] == 0 || z[17] > kRingElemPerLane * kRingBlock))
     return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan has %lld elements: the fused load "
                 "vector stages at most %d", (long long)z[17], kRingElemPerLane * kRingBlock);
@@ -211,6 +274,17 @@ static int launch_rings(const RingLaunch &L) {
   void *params[] = {&a};
   hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, L.stream);
   if (e != hipSuccess) return fail(TFEM_ERR_HIP, "ring kernel launch: %s", hipGetErrorString(e));
+  if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours
+    const dim3 lgrid{unsigned((z[23] + kRingBlock - 1) / kRingBlock)};
+    if (mass)
+      hipLaunchKernelGGL((k_p1_long_rows<T, true>), lgrid, block, 0, L.stream, a.coords, a.plan, unsigned(z[22]),
+                         int(z[23]), a.vals, a.stiff_w, a.mass_d, a.mass_o);
+    else
+      hipLaunchKernelGGL((k_p1_long_rows<T, false>), lgrid, block, 0, L.stream, a.coords, a.plan, unsigned(z[22]),
+                         int(z[23]), a.vals, a.stiff_w, a.mass_d, a.mass_o);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(TFEM_ERR_HIP, "long-row kernel launch: %s", hipGetErrorString(e));
+  }
   return TFEM_OK;
 }
 

@@ -21,6 +21,14 @@
 //   position of column n_i inside the row
 //                           : SLOTS 7 : (w3 >> 3 i) & 7
 //                             SLOTS 15: i < 8 ? (w6 >> 4 i) & 15 : (w7 >> 4 (i - 8)) & 15
+// LONG ROWS (plans of unstructured meshes, mode "long", the default when a row has more than 8
+// entries): the tiles keep the 4-dword records; a vertex with 8 .. 15 neighbours keeps its place
+// in its tile as a row of length zero (k = 0, w3 = 0x80000000 | entries of the row: the rows
+// behind it in the wave start that many entries later) and is listed in `long_rows`, 24 dwords
+// each, written by a launch of its own (one lane per long row, global ids):
+//   vertex id, CSR offset of the row, k | position of the diagonal << 8, triangle flags (2 bits per
+//   slot), 15 neighbour vertex ids, positions of the 15 neighbour columns (4 bits each, 2 dwords)
+// TFEM_RING_LONG=0 keeps the 8-dword 15-slot records for every row instead.
 // Supported fans: one closed cycle (interior vertex) or any number of open chains (boundary
 // vertex, several fans meeting in a vertex).  An edge with three or more triangles, a
 // duplicated or degenerate triangle, or a closed cycle beside another fan is reported as
@@ -66,12 +74,14 @@ struct RingPlan {
   // ids of the element in its own local order, 10 bits each -- what the kernel needs to form the
   // integration points of the element from the coordinates it holds in LDS (source programs)
   std::vector<uint32_t> tile_tverts;
+  std::vector<uint32_t> long_rows;  // 24 dwords per vertex with 8 .. 15 neighbours (slots == 7 plans)
   int32_t max_n_elem = 0;
   bool elems_staged = true;  // false: some tile has more than kRingElemCap elements
   std::vector<int32_t> vert_gid;  // global id of every tile-local vertex, owned rows first
   int32_t max_n_vert = 0, max_n_own = 0, max_row_len = 0, max_n_halo = 0;
   int64_t n_tiles = 0;
   bool chunked = false;           // every wave's 64 rows are 64 consecutive vertices
+  bool long_mode = false;         // 4-dword records + long rows instead of 8-dword records
 };
 
 namespace {
@@ -243,7 +253,7 @@ struct TileSpec {
 // share starts inside the arena.
 struct TileArena {
   std::vector<int32_t> vert_gid, rowstart, tile_elems;
-  std::vector<uint32_t> rows, row_ecodes, tile_tverts;
+  std::vector<uint32_t> rows, row_ecodes, tile_tverts, long_rows;
 };
 
 struct TileOut {
@@ -264,8 +274,8 @@ struct EmitScratch {
 // first reference) and writes its row records, element list, element vertex table and slot codes.
 template <typename I>
 void emit_tile(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const int64_t *rowptr,
-               const int32_t *colind, int slots, int words, bool elem_ranges, const TileSpec &spec,
-               EmitScratch &sc, TileArena &ar, TileOut &out) {
+               const int32_t *colind, int slots, int words, bool elem_ranges, bool long_mode,
+               const TileSpec &spec, EmitScratch &sc, TileArena &ar, TileOut &out) {
   const std::vector<int32_t> &owned = spec.owned;
   const int n_own = int(owned.size());
   out.n_own = n_own;
@@ -303,7 +313,7 @@ void emit_tile(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const 
       out.bad_len = -1;
       return;
     }
-    if (len != (fan.k ? fan.k + 1 : 0) || fan.k > slots) {
+    if (len != (fan.k ? fan.k + 1 : 0) || (fan.k > slots && !(long_mode && fan.k <= 15))) {
       out.status = TFEM_ERR_UNSUPPORTED;
       out.bad_vertex = u;
       out.bad_len = len;
@@ -315,6 +325,29 @@ void emit_tile(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const 
     const int32_t *last = colind + rowptr[u + 1];
     const uint32_t k = uint32_t(fan.k);
     const uint32_t dpos = len ? uint32_t(std::lower_bound(first, last, u) - first) : 0u;
+    if (fan.k > slots) {
+      // a long row: a record of length zero in the tile, the row itself in the long-row list
+      w[3] = 0x80000000u | uint32_t(len);
+      uint32_t r[24] = {0};
+      r[0] = uint32_t(u);
+      r[1] = uint32_t(rowptr[u]);
+      r[2] = k | dpos << 8;
+      for (int i = 0; i < fan.k; ++i) {
+        r[3] |= uint32_t(fan.flag[i]) << (2 * i);
+        r[4 + i] = uint32_t(fan.nb[i]);
+        const uint32_t pos = uint32_t(std::lower_bound(first, last, fan.nb[i]) - first);
+        r[19 + i / 8] |= pos << (4 * (i % 8));
+      }
+      ar.long_rows.insert(ar.long_rows.end(), r, r + 24);
+      ar.rows.insert(ar.rows.end(), w, w + words);
+      ar.rowstart.push_back(int32_t(rowptr[u]));
+      for (int i = 0; i < fan.k; ++i)  // its elements still belong to the tile (load vector)
+        if (fan.flag[i] != 0 && !sc.elems.has(fan.elem[i])) {
+          sc.elems.put(fan.elem[i], 0);
+          sc.elems_here.push_back(fan.elem[i]);
+        }
+      continue;
+    }
     for (int i = 0; i < fan.k; ++i) {
       const uint32_t lid = uint32_t(sc.verts.get(fan.nb[i]));
       const uint32_t pos = uint32_t(std::lower_bound(first, last, fan.nb[i]) - first);
@@ -436,8 +469,8 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
     ar.tile_tverts.reserve(rows_here * 3);
     EmitScratch sc;
     for (int64_t k = b; k < e; ++k)
-      emit_tile(conn, adj_ptr, adj, rowptr, colind, plan.slots, plan.words, elem_ranges, specs[size_t(k)], sc, ar,
-                outs[size_t(k)]);
+      emit_tile(conn, adj_ptr, adj, rowptr, colind, plan.slots, plan.words, elem_ranges, plan.long_mode,
+                specs[size_t(k)], sc, ar, outs[size_t(k)]);
   }, 8);
   for (const TileOut &o : outs)
     if (o.status != TFEM_OK) {
@@ -471,6 +504,9 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
   plan.row_ecodes.resize(size_t(base_row[size_t(max_threads)]) * size_t(ewords));
   plan.tile_elems.resize(size_t(base_elem[size_t(max_threads)]));
   plan.tile_tverts.resize(size_t(base_tv[size_t(max_threads)]));
+  plan.long_rows.clear();
+  for (int t = 0; t < max_threads; ++t)
+    plan.long_rows.insert(plan.long_rows.end(), arenas[size_t(t)].long_rows.begin(), arenas[size_t(t)].long_rows.end());
   {
     std::vector<std::thread> pool;
     for (int t = 0; t < max_threads; ++t)
@@ -536,8 +572,10 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   if (longest > 16)
     return fail(TFEM_ERR_UNSUPPORTED, "a row has %lld entries (> 16)", (long long)longest);
   plan.max_row_len = int32_t(longest);
-  plan.slots = longest <= 8 ? 7 : 15;
-  plan.words = longest <= 8 ? 4 : 8;
+  const char *long_env = std::getenv("TFEM_RING_LONG");
+  plan.long_mode = longest > 8 && !(long_env && long_env[0] == '0');
+  plan.slots = (longest <= 8 || plan.long_mode) ? 7 : 15;
+  plan.words = plan.slots == 7 ? 4 : 8;
   double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
   for (int64_t v = 0; v < n_verts; ++v)
     for (int c = 0; c < 2; ++c) {
@@ -578,6 +616,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.rowstart.clear();
     plan.tile_elems.clear();
     plan.tile_tverts.clear();
+    plan.long_rows.clear();
     plan.row_ecodes.clear();
     plan.vert_gid.clear();
     plan.max_n_elem = 0;
@@ -775,13 +814,13 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[7] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+  const int64_t bytes[8] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
                             int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
                             int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4,
-                            int64_t(p.tile_tverts.size()) * 4};
-  const int slot_of[7] = {8, 9, 10, 11, 15, 16, 20};
+                            int64_t(p.tile_tverts.size()) * 4, int64_t(p.long_rows.size()) * 4};
+  const int slot_of[8] = {8, 9, 10, 11, 15, 16, 20, 22};
   int64_t off = 0;
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < 8; ++i) {
     layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
@@ -790,6 +829,7 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[18] = p.elems_staged ? 1 : 0;
   layout[19] = int64_t(p.tile_elems.size());
   layout[21] = int64_t(p.tile_tverts.size());
+  layout[23] = int64_t(p.long_rows.size() / 24);
   layout[13] = p.chunked ? 1 : 0;
   layout[14] = p.max_n_halo;
 }
@@ -849,7 +889,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   // the arrays, each cut into pieces for the threads; the padding between them and the 64 spare
   // bytes at the end are zero
   struct Part { int64_t off; const void *src; int64_t bytes; };
-  const Part parts[7] = {
+  const Part parts[8] = {
       {layout[8], p->desc.data(), int64_t(p->desc.size()) * 4},
       {layout[9], p->rows.data(), int64_t(p->rows.size()) * 4},
       {layout[10], p->rowstart.data(), int64_t(p->rowstart.size()) * 4},
@@ -857,6 +897,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
       {layout[15], p->row_ecodes.data(), int64_t(p->row_ecodes.size()) * 4},
       {layout[16], p->tile_elems.data(), int64_t(p->tile_elems.size()) * 4},
       {layout[20], p->tile_tverts.data(), int64_t(p->tile_tverts.size()) * 4},
+      {layout[22], p->long_rows.data(), int64_t(p->long_rows.size()) * 4},
   };
   for (const Part &part : parts) {
     const int64_t padded = (part.bytes + 15) & ~int64_t(15);

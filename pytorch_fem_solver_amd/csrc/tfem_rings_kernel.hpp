@@ -231,6 +231,36 @@ __device__ __forceinline__ void ring_store_run1(const T *stage, int total, int d
   }
 }
 
+// One run per wave EXCEPT for long rows (plans of unstructured meshes: vertices with 8 .. 15
+// neighbours are written by k_p1_long_rows): their entries are not in the stage, the rows behind
+// them start further on in the CSR array.  `pre` = stage index of the lane's row, `csr` = CSR
+// offset of the lane's row; the stage is streamed out piece by piece between the long rows.
+template <typename T>
+__device__ __forceinline__ void ring_store_pieces(const T *stage, int total, int pre, int csr, bool is_long,
+                                                  ring_rsrc_t r_vals) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long holes = __ballot(is_long);
+  int first_lane = 0;
+  for (;;) {
+    const int stop_lane = holes ? __builtin_ctzll(holes) : 64;
+    if (first_lane < stop_lane) {
+      const int b = __builtin_amdgcn_readlane(pre, first_lane);
+      const int e = stop_lane < 64 ? __builtin_amdgcn_readlane(pre, stop_lane) : total;
+      const int delta = __builtin_amdgcn_readlane(csr, first_lane) - b;
+      for (int s0 = b + lane; s0 < e; s0 += 64) {
+        const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
+        if constexpr (sizeof(T) == 8)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, stage[s0]), r_vals, byte, 0, kStreamNT);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, stage[s0]), r_vals, byte, 0, kStreamNT);
+      }
+    }
+    if (!holes) break;
+    holes &= holes - 1;
+    first_lane = stop_lane + 1;
+  }
+}
+
 // General form: the rows of a wave form several runs (one per grid line of a Z-order tile;
 // one per row for a numbering without locality).  Per run, as above.
 template <typename T, int SLOTS, bool DBG = false>
@@ -776,7 +806,15 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     if (KMAT && !(DBG && (a.flags & 8))) {
       if (CHUNK) {  // one run per wave by construction, its CSR offset in the descriptor
         __builtin_amdgcn_wave_barrier();
-        ring_store_run1<T, SLOTS, DBG>(my_stage, total, dc.rs0, r_vals, a.flags);
+        // long rows (k = 0, bit 31 of the last record word, the row's length below it) leave holes
+        const bool is_long = SLOTS == 7 && dc.row0 + lane < dc.row1 && kk == 0 && (rec.w[3] >> 31) != 0u;
+        if (SLOTS != 7 || __ballot(is_long) == 0ull) {
+          ring_store_run1<T, SLOTS, DBG>(my_stage, total, dc.rs0, r_vals, a.flags);
+        } else {
+          const int true_len = is_long ? int(rec.w[3] & 0x7FFFFFFFu) : len_c;
+          const int csr = dc.rs0 + wave_inclusive_scan(true_len) - true_len;
+          ring_store_pieces<T>(my_stage, total, pre, csr, is_long, r_vals);
+        }
         __builtin_amdgcn_wave_barrier();
       } else {
         ring_store<T, SLOTS, DBG>(my_stage, total, pre, rowstart, len_c, r_vals, a.flags);

@@ -45,6 +45,7 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
     vals = np.full(nnz, np.nan)
     writes = np.zeros(nnz, dtype=np.int64)
     covered = 0
+    long_seen = {}
     fvec = np.full(coords.shape[0], np.nan) if (fq is not None or source is not None) else None
     ewords = (12 * slots + 31) // 32  # packed 12-bit slot codes
     row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
@@ -97,8 +98,16 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
             if b > a:  # what the consecutive-vertex kernel takes from the descriptor
                 assert d[8 + w] == gid[a] and d[12 + w] == rowstart[a]
         covered += n_own
+        raw = rows[row_off:row_off + n_own]
         for r in range(n_own):
             k = int(rec["k"][r])
+            if k == 0 and slots == 7 and int(raw[r][3]) >> 31:
+                # a long row (8 .. 15 neighbours): written from the long-row list below; its sum of
+                # the load vector comes from the element-form accumulators (source programs only)
+                long_seen[int(gid[r])] = int(raw[r][3]) & 0x7FFFFFFF
+                if fvec is not None:
+                    fvec[gid[r]] = facc_tile[r] if facc_tile is not None else np.nan
+                continue
             if k == 0:
                 if fvec is not None:
                     fvec[gid[r]] = 0.0
@@ -136,6 +145,33 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
             writes[targets] += 1
             if fvec is not None:
                 fvec[gid[r]] = facc if facc_tile is None else facc_tile[r]
+    # ---- long rows: global ids, as k_p1_long_rows walks them
+    long_rows = plan.get("long_rows", np.zeros(0, dtype=np.uint32)).reshape(-1, 24)
+    assert {int(r[0]): None for r in long_rows}.keys() == long_seen.keys() and len(long_rows) == len(long_seen)
+    for r in long_rows:
+        v, start = int(r[0]), int(r[1])
+        k, dpos, flagword = int(r[2]) & 0xFF, int(r[2]) >> 8, int(r[3])
+        assert 8 <= k <= 15 and long_seen[v] == k + 1
+        ids = [int(r[4 + i]) for i in range(k)]
+        pos = [(int(r[19 + i // 8]) >> (4 * (i % 8))) & 15 for i in range(k)]
+        e = coords[ids] - coords[v]
+        off, diag = np.zeros(k), 0.0
+        for i in range(k):
+            nxt = 0 if i + 1 == k else i + 1
+            flag = (flagword >> (2 * i)) & 3
+            if flag == 0:
+                continue
+            dvec = e[nxt] - e[i]
+            cross = e[i, 0] * e[nxt, 1] - e[i, 1] * e[nxt, 0]
+            sdet = cross if flag == 1 else -cross
+            cs = stiff_w / sdet
+            diag += cs * dvec.dot(dvec) + mass_d * sdet
+            off[i] += -cs * dvec.dot(e[nxt]) + mass_o * sdet
+            off[nxt] += cs * dvec.dot(e[i]) + mass_o * sdet
+        targets = np.concatenate([start + np.asarray(pos), [start + dpos]])
+        assert np.unique(targets).size == k + 1 and targets.max() < start + k + 1
+        vals[targets] = np.concatenate([off, [diag]])
+        writes[targets] += 1
     if fvec is not None:
         return vals, writes, covered, fvec
     return vals, writes, covered

@@ -583,7 +583,12 @@ def test_fused_system_launch_matches_separate_forms(order, kernel):
     out = (torch.full_like(vals, float("nan")), torch.full_like(f.view(-1), float("nan")))
     vals2, f2 = basis._engine.assemble_system(1.0, 1.0, fq, out=out)
     assert vals2.data_ptr() == out[0].data_ptr() and f2.data_ptr() == out[1].data_ptr()
-    assert torch.equal(vals2.view(-1), vals.view(-1)) or kernel == "tiles"  # LDS atomics: order varies
+    # bit for bit the same from the row form; the tile kernel's LDS atomics add in varying order, and
+    # so does this launch on a ring plan with long rows (source VALUES then take the tile kernel:
+    # only a source PROGRAM runs inside the ring launch there)
+    fq_rings = kernel != "tiles" and basis._engine.ring_plan()["fq_ok"]
+    assert fq_rings == (kernel != "tiles" and int(basis._engine.ring_plan()["layout"][23]) == 0)
+    assert torch.equal(vals2.view(-1), vals.view(-1)) or not fq_rings
     assert scaled_error(vals2.cpu(), vals.cpu()) <= 1e-14 and scaled_error(f2.cpu().view(-1), f.cpu().view(-1)) <= 1e-14
     with pytest.raises(ValueError):
         basis._engine.assemble_system(1.0, 1.0, fq, out=(out[0][:-1], out[1]))

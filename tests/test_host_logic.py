@@ -208,7 +208,8 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
                           own_cap=64 if kind != "delaunay" else None,
                           vert_cap=160 if kind != "delaunay" else None)
     longest = int(np.diff(rowptr).max())
-    assert plan["slots"] == (7 if longest <= 8 else 15)
+    assert plan["slots"] == 7  # rows of more than 8 entries: long rows, not 8-dword records
+    assert (plan["long_rows"].size > 0) == (longest > 8)
     weights = np.asarray(orc.gauss_rule(3)[1]).reshape(-1)
     bary = np.asarray(orc.barycentric_coordinates(orc.gauss_rule(3)[0])).reshape(-1, 3)
     w = 0.5 * weights.sum()
@@ -226,9 +227,13 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
     local, _ = orc.p1_assemble(mesh["vertices"], mesh["triangles"], 3, form)
     want = orc.assemble_csr_values(local, slots.reshape(-1, 3, 3), colind.shape[0])
     assert scaled_error(vals, want) <= 1e-13
-    # the load vector through the plan's row_elems (element and local index per slot)
+    # the load vector through the plan's row_elems (element and local index per slot); a plan with
+    # long rows (Delaunay meshes) serves source programs only (below)
     want_f = orc.assemble_linear(fl, mesh["triangles"], nv).reshape(-1)
-    assert scaled_error(fvec, want_f) <= 1e-13
+    has_long = plan["long_rows"].size > 0
+    assert has_long == kind.startswith("delaunay")
+    if not has_long:
+        assert scaled_error(fvec, want_f) <= 1e-13
     # the same vector with the source evaluated per tile from the tile's own coordinates through
     # the element vertex table (what the SRC kernels do), program of tests/test_assembly.py:75-77
     _, _, _, fsrc = run_ring_plan(plan, mesh["vertices"], colind.shape[0], w, md, mo, lamw=lamw,
@@ -365,7 +370,8 @@ def test_random_meshes_through_the_plan_emulators(seed):
         assert covered == nv and (writes == 1).all()
         assert scaled_error(vals, want) <= 1e-12
         fl = orc.integrate_local(orc.integrand_load(geo), geo["dx"])
-        assert scaled_error(fvec, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
+        if plan["long_rows"].size == 0:
+            assert scaled_error(fvec, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
         _, _, _, fsrc = run_ring_plan(plan, verts, colind.shape[0], 0.5 * weights.sum(), lamw=lamw,
                                       conn=tris, source=_SIN_SIN_PROGRAM, lam=bary.T)
         assert scaled_error(fsrc, orc.assemble_linear(fl, tris, nv).reshape(-1)) <= 1e-12
@@ -684,8 +690,8 @@ def test_bench_reads_the_committed_profiles():
 def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest():
     """The once-per-mesh builders (CSR pattern, slot map, ring plan) are multi-threaded
     (csrc/tfem_threads.hpp): 1, 3 and the default number of threads give identical bytes, and the
-    bytes are the ones the sequential round-1 builder produced for these meshes (digests taken
-    from that build before the builders were restructured)."""
+    bytes are the ones the sequential builder produced for these meshes (digests taken from that
+    build before the builders were restructured)."""
     import hashlib
 
     from pytorch_fem_solver_amd import meshgen
@@ -699,6 +705,8 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
         "Dnative": (delaunay, "d789ebac29155b24", None),
     }
     saved = os.environ.get("TFEM_HOST_THREADS")
+    saved_long = os.environ.get("TFEM_RING_LONG")
+    os.environ["TFEM_RING_LONG"] = "0"  # the digests are those of the 8-dword records on the Delaunay meshes
     try:
         for name, (mesh, plan_digest, pattern_digest) in cases.items():
             nv = mesh["vertices"].shape[0]
@@ -716,8 +724,22 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
             got_plan, got_sym = next(iter(seen))
             assert got_plan == plan_digest, name
             assert pattern_digest is None or got_sym == pattern_digest
+        # the plans with long rows (the default on these meshes): thread-count invariance
+        os.environ.pop("TFEM_RING_LONG", None)
+        for name in ("Dmorton", "Dnative"):
+            mesh = cases[name][0]
+            nv = mesh["vertices"].shape[0]
+            rowptr, colind, _ = symbolic_host(mesh["triangles"], nv)
+            seen = set()
+            for threads in ("1", "5"):
+                os.environ["TFEM_HOST_THREADS"] = threads
+                plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind)
+                assert plan["slots"] == 7 and plan["long_rows"].size > 0
+                seen.add(hashlib.sha256(plan["blob"].tobytes()).hexdigest())
+            assert len(seen) == 1, name
     finally:
-        if saved is None:
-            os.environ.pop("TFEM_HOST_THREADS", None)
-        else:
-            os.environ["TFEM_HOST_THREADS"] = saved
+        for key, value in (("TFEM_HOST_THREADS", saved), ("TFEM_RING_LONG", saved_long)):
+            if value is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = value
