@@ -21,14 +21,13 @@
 //   position of column n_i inside the row
 //                           : SLOTS 7 : (w3 >> 3 i) & 7
 //                             SLOTS 15: i < 8 ? (w6 >> 4 i) & 15 : (w7 >> 4 (i - 8)) & 15
-// LONG ROWS (plans of unstructured meshes, mode "long", the default when a row has more than 8
-// entries): the tiles keep the 4-dword records; a vertex with 8 .. 15 neighbours keeps its place
+// LONG ROWS (plans of unstructured meshes, TFEM_RING_LONG=1; not the default, see build_rings):
+// the tiles keep the 4-dword records; a vertex with 8 .. 15 neighbours keeps its place
 // in its tile as a row of length zero (k = 0, w3 = 0x80000000 | entries of the row: the rows
 // behind it in the wave start that many entries later) and is listed in `long_rows`, 24 dwords
 // each, written by a launch of its own (one lane per long row, global ids):
 //   vertex id, CSR offset of the row, k | position of the diagonal << 8, triangle flags (2 bits per
 //   slot), 15 neighbour vertex ids, positions of the 15 neighbour columns (4 bits each, 2 dwords)
-// TFEM_RING_LONG=0 keeps the 8-dword 15-slot records for every row instead.
 // Supported fans: one closed cycle (interior vertex) or any number of open chains (boundary
 // vertex, several fans meeting in a vertex).  An edge with three or more triangles, a
 // duplicated or degenerate triangle, or a closed cycle beside another fan is reported as
@@ -572,8 +571,13 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   if (longest > 16)
     return fail(TFEM_ERR_UNSUPPORTED, "a row has %lld entries (> 16)", (long long)longest);
   plan.max_row_len = int32_t(longest);
+  // Measured (profiles/r02_delaunay_long_rows.log, Delaunay mesh of 1e6 / 5e6 points): the tile
+  // kernel gets 20 % faster with 4-dword records (21.8 against 27.1 us at 2e6 elements), but the
+  // long-row launch -- 13 % of the rows, 96-byte records, coordinates by global ids, 72-byte
+  // pieces of the value array -- costs more than that gains (31 us): 8-dword records stay the
+  // default; TFEM_RING_LONG=1 builds the plan with long rows.
   const char *long_env = std::getenv("TFEM_RING_LONG");
-  plan.long_mode = longest > 8 && !(long_env && long_env[0] == '0');
+  plan.long_mode = longest > 8 && long_env && long_env[0] == '1';
   plan.slots = (longest <= 8 || plan.long_mode) ? 7 : 15;
   plan.words = plan.slots == 7 ? 4 : 8;
   double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};

@@ -584,8 +584,8 @@ def test_fused_system_launch_matches_separate_forms(order, kernel):
     vals2, f2 = basis._engine.assemble_system(1.0, 1.0, fq, out=out)
     assert vals2.data_ptr() == out[0].data_ptr() and f2.data_ptr() == out[1].data_ptr()
     # bit for bit the same from the row form; the tile kernel's LDS atomics add in varying order, and
-    # so does this launch on a ring plan with long rows (source VALUES then take the tile kernel:
-    # only a source PROGRAM runs inside the ring launch there)
+    # so does this launch on a ring plan with long rows (TFEM_RING_LONG=1; source VALUES then take the
+    # tile kernel: only a source PROGRAM runs inside the ring launch there)
     fq_rings = kernel != "tiles" and basis._engine.ring_plan()["fq_ok"]
     assert fq_rings == (kernel != "tiles" and int(basis._engine.ring_plan()["layout"][23]) == 0)
     assert torch.equal(vals2.view(-1), vals.view(-1)) or not fq_rings
@@ -598,6 +598,37 @@ def test_fused_system_launch_matches_separate_forms(order, kernel):
     basis2 = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, order))
     basis2._engine.kernel = "atomic"
     assert scaled_error(basis2._engine.load(fq).cpu(), f.cpu()) <= 1e-13
+
+
+@pytest.mark.parametrize("numbering", ["morton", "native"])
+def test_ring_plan_variant_with_long_rows(numbering, monkeypatch):
+    """TFEM_RING_LONG=1: 4-dword records in the tiles, the vertices with 8 .. 15 neighbours through
+    k_p1_long_rows, holes in the tile kernel's output runs (consecutive-vertex tiles) / its run
+    detection (Z-order tiles).  Not the default (it is slower, profiles/r02_delaunay_long_rows.log);
+    kept correct."""
+    from pytorch_fem_solver_amd import meshgen
+
+    monkeypatch.setenv("TFEM_RING_LONG", "1")
+    mesh_np = meshgen.delaunay_square(7000, 21)
+    if numbering == "morton":
+        mesh_np = meshgen.permute_mesh(mesh_np, vertex_order=meshgen.morton_order(mesh_np["vertices"]))
+    nv = mesh_np["vertices"].shape[0]
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+    eng = basis._engine
+    eng.kernel = "rings"
+    plan = eng.ring_plan()
+    assert int(plan["layout"][6]) == 7 and int(plan["layout"][23]) > 100 and plan["chunked"] == (numbering == "morton")
+    _, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
+    for form, ab in (("stiffness", (1.0, 0.0)), ("stiffness_mass", (1.0, 1.0)), ("mass", (0.0, 1.0))):
+        local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, form)
+        want = orc.assemble_csr_values(local, slots, colind.shape[0])
+        got = torch.full((colind.shape[0],), float("nan"))
+        eng._assemble_rings(*ab, out=(got, None))
+        assert scaled_error(got.cpu(), want) <= TOL, form
+    f = basis.integrate_linear_form(load)  # the source program inside the launch
+    fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, "load")
+    assert scaled_error(f.cpu(), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
+    assert not plan["fq_ok"]  # source VALUES do not take this plan
 
 
 def test_engine_picks_the_tile_kernel_for_a_numbering_without_locality():

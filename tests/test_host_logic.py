@@ -194,13 +194,21 @@ def _ring_case(kind):
     return mesh
 
 
-@pytest.mark.parametrize("kind", ["structured", "tiny", "clockwise_mixed", "delaunay", "delaunay_shuffled"])
+@pytest.mark.parametrize("kind", ["structured", "tiny", "clockwise_mixed", "delaunay", "delaunay_shuffled",
+                                  "delaunay+long_rows", "delaunay_shuffled+long_rows"])
 @pytest.mark.parametrize("form", ["stiffness", "stiffness_mass"])
-def test_ring_plan_is_a_valid_exact_cover(kind, form):
+def test_ring_plan_is_a_valid_exact_cover(kind, form, monkeypatch):
     """Walk the ring plan like k_p1_rings does (tests/ring_emulator.py): every CSR entry is
-    written exactly once and the values equal the oracle's."""
+    written exactly once and the values equal the oracle's.  +long_rows: the plan variant
+    TFEM_RING_LONG=1 (4-dword records, vertices with 8 .. 15 neighbours in the long-row list)."""
     from pytorch_fem_solver_amd.basis.engine import ring_plan_host, symbolic_host
 
+    kind, _, variant = kind.partition("+")
+    long_rows = variant == "long_rows"
+    if long_rows:
+        monkeypatch.setenv("TFEM_RING_LONG", "1")
+    else:
+        monkeypatch.delenv("TFEM_RING_LONG", raising=False)
     mesh = _ring_case(kind)
     nv = mesh["vertices"].shape[0]
     rowptr, colind, slots = symbolic_host(mesh["triangles"], nv)
@@ -208,8 +216,8 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
                           own_cap=64 if kind != "delaunay" else None,
                           vert_cap=160 if kind != "delaunay" else None)
     longest = int(np.diff(rowptr).max())
-    assert plan["slots"] == 7  # rows of more than 8 entries: long rows, not 8-dword records
-    assert (plan["long_rows"].size > 0) == (longest > 8)
+    assert plan["slots"] == (7 if longest <= 8 or long_rows else 15)
+    assert (plan["long_rows"].size > 0) == (longest > 8 and long_rows)
     weights = np.asarray(orc.gauss_rule(3)[1]).reshape(-1)
     bary = np.asarray(orc.barycentric_coordinates(orc.gauss_rule(3)[0])).reshape(-1, 3)
     w = 0.5 * weights.sum()
@@ -231,7 +239,6 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form):
     # long rows (Delaunay meshes) serves source programs only (below)
     want_f = orc.assemble_linear(fl, mesh["triangles"], nv).reshape(-1)
     has_long = plan["long_rows"].size > 0
-    assert has_long == kind.startswith("delaunay")
     if not has_long:
         assert scaled_error(fvec, want_f) <= 1e-13
     # the same vector with the source evaluated per tile from the tile's own coordinates through
@@ -706,7 +713,7 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
     }
     saved = os.environ.get("TFEM_HOST_THREADS")
     saved_long = os.environ.get("TFEM_RING_LONG")
-    os.environ["TFEM_RING_LONG"] = "0"  # the digests are those of the 8-dword records on the Delaunay meshes
+    os.environ.pop("TFEM_RING_LONG", None)  # the digests are those of the default plans (8-dword records)
     try:
         for name, (mesh, plan_digest, pattern_digest) in cases.items():
             nv = mesh["vertices"].shape[0]
@@ -724,8 +731,8 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
             got_plan, got_sym = next(iter(seen))
             assert got_plan == plan_digest, name
             assert pattern_digest is None or got_sym == pattern_digest
-        # the plans with long rows (the default on these meshes): thread-count invariance
-        os.environ.pop("TFEM_RING_LONG", None)
+        # the plans with long rows (TFEM_RING_LONG=1): thread-count invariance
+        os.environ["TFEM_RING_LONG"] = "1"
         for name in ("Dmorton", "Dnative"):
             mesh = cases[name][0]
             nv = mesh["vertices"].shape[0]
