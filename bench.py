@@ -535,6 +535,33 @@ def main():
             line["api_ms_per_step"] = (time.perf_counter() - t1) * 1e3 / 100
             line["api_note"] = ("integrate_bilinear_form(v_grad @ v_grad.mT, layout='csr') + integrate_linear_form("
                                 "f(x_q) * v) per call at this mesh: tracer, K launch, f launch with the source inside")
+        if world == 1:
+            # the same launch with other sources: what the source itself costs (the launch is
+            # bound by fp64 vector issue), and with pre-evaluated source values
+            # streamed from HBM (round 1's step: the evaluation of f was outside the timed region)
+            x_sym, y_sym = forms.SourceExpr(basis, ("x",)), forms.SourceExpr(basis, ("y",))
+            variants = {
+                "constant f = 1": forms.SourceExpr(basis, ("c", 1.0)).program(),
+                "polynomial f = x y + 1": (x_sym * y_sym + 1.0).program(),
+            }
+            sources = {"2 pi^2 sin(pi x) sin(pi y) (the step)": {"kernel_ms": k_ms, "frac": achieved / HBM_PEAK_GBS}}
+            for label, prog in variants.items():
+                for _ in range(20):
+                    engine.assemble_system(1.0, 0.0, source=prog)
+                torch.cuda.synchronize()
+                ms = event_ms(lambda: engine.assemble_system(1.0, 0.0, source=prog), 30, batches=3)
+                sources[label] = {"kernel_ms": ms, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            fq = engine.source_values(program)
+            for _ in range(20):
+                engine.assemble_system(1.0, 0.0, fq)
+            torch.cuda.synchronize()
+            ms = event_ms(lambda: engine.assemble_system(1.0, 0.0, fq), 30, batches=3)
+            sources["source values from HBM (f evaluated beforehand, 8 Q B/element more)"] = {
+                "kernel_ms": ms, "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ms = event_ms(lambda: engine.source_values(program), 30, batches=3)
+            sources["tfem_source_eval alone (f at the integration points -> HBM)"] = {"kernel_ms": ms}
+            del fq
+            line["roofline"]["sources"] = sources
         if world == 1 and not args.no_other_configs:
             line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3()}
             line["other_configs"].update(delaunay_configs(args.delaunay_points, args.order))

@@ -317,65 +317,52 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
   }
 }
 
-// Vertex rows with 8 .. 15 neighbours: one lane per row, everything by global ids (the rows are
-// scattered over the mesh: ~10 % of the vertices of a Delaunay mesh).  The walk around the fan is
-// the one of the tile kernel; an entry is written as soon as both triangles that touch its
-// column have been seen, only slot 0 waits for the triangle that closes the fan.
+// Vertex rows with 8 .. 15 neighbours: SIXTEEN lanes per row, lane i = slot i of the fan (the
+// rows are scattered over the mesh -- ~13 % of the vertices of a Delaunay mesh -- so everything
+// goes by global ids).  A lane evaluates its slot's triangle, takes what the previous slot's
+// triangle adds to its own column from the lane before it (the first slot from slot k - 1: the
+// fan closes there, or that slot has no triangle), and writes its three entries; the diagonal is
+// the sum over the sixteen lanes.  No loop, no serial chain of dependent loads.
 template <typename T, bool MASS>
 __global__ __launch_bounds__(kP2Block) void k_p2_long_rows(const P2RowArgs<T> a, unsigned off_long, int n_long) {
-  const int row = int(blockIdx.x) * kP2Block + int(threadIdx.x);
-  if (row >= n_long) return;
-  const uint32_t *rec = reinterpret_cast<const uint32_t *>(a.plan + off_long) + 32 * size_t(row);
+  const int gtid = int(blockIdx.x) * kP2Block + int(threadIdx.x);
+  const int row = gtid >> 4, i = gtid & 15;
+  const bool live = row < n_long;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(a.plan + off_long) + 32 * size_t(live ? row : 0);
   const uint32_t v = rec[0];
-  T *out = a.vals + rec[1];
   const int k = int(rec[2] & 0xFFu);
   const int dpos = int(rec[2] >> 8);
-  const uint32_t flags = rec[3];
-  auto field = [&](int f) { return int((rec[19 + f / 5] >> (6 * (f % 5))) & 63u); };
+  const bool slot = live && i < k;
+  const uint32_t flag = slot ? (rec[3] >> (2 * i)) & 3u : 0u;
+  const int nxt = i + 1 == k ? 0 : i + 1;
+  const uint32_t g0 = rec[4 + (slot ? i : 0)], g1 = rec[4 + (slot ? nxt : 0)];
   const T xv = a.coords[2 * size_t(v)], yv = a.coords[2 * size_t(v) + 1];
-  uint32_t g = rec[4];
-  T ecx = a.coords[2 * size_t(g)] - xv, ecy = a.coords[2 * size_t(g) + 1] - yv;
-  T qc = ecx * ecx + ecy * ecy;
-  const T e0x = ecx, e0y = ecy, q0 = qc;
-  T diag = T(0), v0 = T(0), ev0 = T(0);   // slot 0's two entries: complete when the fan closes
-  T vcarry = T(0), ecarry = T(0);         // what slot i - 1's triangle added to slot i
-  for (int i = 0; i < k; ++i) {
-    const bool wraps = i + 1 == k;
-    T enx, eny, qn;
-    if (wraps) {
-      enx = e0x, eny = e0y, qn = q0;
-    } else {
-      g = rec[5 + i];
-      enx = a.coords[2 * size_t(g)] - xv;
-      eny = a.coords[2 * size_t(g) + 1] - yv;
-      qn = enx * enx + eny * eny;
-    }
-    const T p = ecx * enx + ecy * eny;
-    const T cross = ecx * eny - ecy * enx;
-    const uint32_t flag = (flags >> (2 * i)) & 3u;
-    T r[6];
-    p2_block_row<T, MASS>(a, qc, qn, p, cross, flag, r);
-    const bool fwd = flag != 2u;
-    diag = diag + r[0];
-    const T vi = vcarry + (fwd ? r[1] : r[2]), ei = ecarry + (fwd ? r[3] : r[5]);
-    vcarry = fwd ? r[2] : r[1];
-    ecarry = fwd ? r[5] : r[3];
-    if (i == 0) {
-      v0 = vi;
-      ev0 = ei;
-    } else {
-      out[field(i)] = vi;
-      out[field(15 + i)] = ei;
-    }
-    if (flag) out[field(30 + i)] = r[4];
-    ecx = enx;
-    ecy = eny;
-    qc = qn;
-  }
-  // the closing triangle's share of slot 0 (zero for an open fan: its last slot has no triangle)
-  out[field(0)] = v0 + vcarry;
-  out[field(15)] = ev0 + ecarry;
-  out[dpos] = diag;
+  const T ecx = a.coords[2 * size_t(g0)] - xv, ecy = a.coords[2 * size_t(g0) + 1] - yv;
+  const T enx = a.coords[2 * size_t(g1)] - xv, eny = a.coords[2 * size_t(g1) + 1] - yv;
+  T r[6];
+  p2_block_row<T, MASS>(a, ecx * ecx + ecy * ecy, enx * enx + eny * eny, ecx * enx + ecy * eny,
+                        ecx * eny - ecy * enx, flag, r);
+  // r: v, p1, p2, edge (v,p1), edge (p1,p2), edge (p2,v); (p1, p2) = (n_i, n_next) for flag 1 and
+  // (n_next, n_i) for flag 2
+  const bool fwd = flag != 2u;
+  const T own_v = fwd ? r[1] : r[2], own_e = fwd ? r[3] : r[5];    // to this slot's columns
+  const T next_v = fwd ? r[2] : r[1], next_e = fwd ? r[5] : r[3];  // to the next slot's columns
+  const int lane = int(threadIdx.x) & 63;
+  const int from = (lane & ~15) + (i == 0 ? (k > 0 ? k - 1 : 0) : i - 1);
+  const T vcol = own_v + __shfl(next_v, from, 64);
+  const T ecol = own_e + __shfl(next_e, from, 64);
+  T diag = r[0];
+  diag = diag + __shfl_xor(diag, 8, 64);
+  diag = diag + __shfl_xor(diag, 4, 64);
+  diag = diag + __shfl_xor(diag, 2, 64);
+  diag = diag + __shfl_xor(diag, 1, 64);
+  if (!slot) return;
+  auto field = [&](int f) { return int((rec[19 + f / 5] >> (6 * (f % 5))) & 63u); };
+  T *out = a.vals + rec[1];
+  out[field(i)] = vcol;
+  out[field(15 + i)] = ecol;
+  if (flag) out[field(30 + i)] = r[4];
+  if (i == 0) out[dpos] = diag;
 }
 
 template <typename T>
@@ -448,7 +435,7 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
     hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, stream);
     if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 row kernel launch: %s", hipGetErrorString(e));
     if (kind == 0 && z[18] > 0) {  // the vertex rows with 8 .. 15 neighbours
-      const dim3 lgrid{unsigned((z[18] + kP2Block - 1) / kP2Block)};
+      const dim3 lgrid{unsigned((16 * z[18] + kP2Block - 1) / kP2Block)};  // sixteen lanes per row
       if (mass)
         hipLaunchKernelGGL((k_p2_long_rows<T, true>), lgrid, block, 0, stream, a, unsigned(z[17]), int(z[18]));
       else

@@ -23,64 +23,54 @@
 
 namespace tfem {
 
-// Rows of vertices with 8 .. 15 neighbours in a plan with long rows (tfem_rings_host.cpp): one
-// lane per row, coordinates by global ids.  The walk around the fan is ring_row's; an entry is
-// written as soon as both triangles that touch its column have been seen, only slot 0 waits for the
-// triangle that closes the fan.  ~10 % of the vertices of a Delaunay mesh.
+// Rows of vertices with 8 .. 15 neighbours in a plan with long rows (tfem_rings_host.cpp):
+// SIXTEEN lanes per row, lane i = slot i of the fan, coordinates by global ids.  A lane
+// evaluates its slot's triangle (ring_row's formulas), takes what the previous slot's triangle
+// adds to its own column from the lane before it (slot 0 from slot k - 1), and writes its entry;
+// the diagonal follows from the sum over the sixteen lanes.
 template <typename T, bool MASS>
 __global__ __launch_bounds__(kRingBlock) void k_p1_long_rows(const T *coords, const unsigned char *plan,
                                                              unsigned off_long, int n_long, T *vals, T stiff_w,
                                                              T mass_d, T mass_o) {
-  const int row = int(blockIdx.x) * kRingBlock + int(threadIdx.x);
-  if (row >= n_long) return;
-  const uint32_t *rec = reinterpret_cast<const uint32_t *>(plan + off_long) + 24 * size_t(row);
+  const int gtid = int(blockIdx.x) * kRingBlock + int(threadIdx.x);
+  const int row = gtid >> 4, i = gtid & 15;
+  const bool live = row < n_long;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(plan + off_long) + 24 * size_t(live ? row : 0);
   const uint32_t v = rec[0];
-  T *out = vals + rec[1];
   const int k = int(rec[2] & 0xFFu);
   const int dpos = int(rec[2] >> 8);
-  const uint32_t flags = rec[3];
-  auto pos = [&](int i) { return int((rec[19 + i / 8] >> (4 * (i % 8))) & 15u); };
+  const bool slot = live && i < k;
+  const uint32_t flag = slot ? (rec[3] >> (2 * i)) & 3u : 0u;
+  const int nxt = i + 1 == k ? 0 : i + 1;
+  const uint32_t g0 = rec[4 + (slot ? i : 0)], g1 = rec[4 + (slot ? nxt : 0)];
   const T xv = coords[2 * size_t(v)], yv = coords[2 * size_t(v) + 1];
-  uint32_t g = rec[4];
-  T ecx = coords[2 * size_t(g)] - xv, ecy = coords[2 * size_t(g) + 1] - yv;
-  T qc = ecx * ecx + ecy * ecy;
-  const T e0x = ecx, e0y = ecy, q0 = qc;
-  T sum = T(0), dsum = T(0), first = T(0), carry = T(0);
-  for (int i = 0; i < k; ++i) {
-    T enx, eny, qn;
-    if (i + 1 == k) {
-      enx = e0x, eny = e0y, qn = q0;
-    } else {
-      g = rec[5 + i];
-      enx = coords[2 * size_t(g)] - xv;
-      eny = coords[2 * size_t(g) + 1] - yv;
-      qn = enx * enx + eny * eny;
-    }
-    const T p = ecx * enx + ecy * eny;
-    const T cross = ecx * eny - ecy * enx;
-    const uint32_t flag = (flags >> (2 * i)) & 3u;
-    const T cs = flag_weight<T>(stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
-    T here = cs * (p - qn), next = cs * (p - qc);  // to column n_i, to column n_next
-    if (MASS) {
-      const T sdet = flag_weight<T>(T(1), flag) * cross;
-      here = here + mass_o * sdet;
-      next = next + mass_o * sdet;
-      dsum = dsum + sdet;
-    }
-    const T entry = carry + here;
-    sum = sum + here + next;
-    carry = next;
-    if (i == 0)
-      first = entry;
-    else
-      out[pos(i)] = entry;
-    ecx = enx;
-    ecy = eny;
-    qc = qn;
+  const T ecx = coords[2 * size_t(g0)] - xv, ecy = coords[2 * size_t(g0) + 1] - yv;
+  const T enx = coords[2 * size_t(g1)] - xv, eny = coords[2 * size_t(g1) + 1] - yv;
+  const T qc = ecx * ecx + ecy * ecy, qn = enx * enx + eny * eny;
+  const T p = ecx * enx + ecy * eny;
+  const T cross = ecx * eny - ecy * enx;
+  const T cs = flag_weight<T>(stiff_w, flag) * fast_rcp<T>(flag ? cross : T(1));
+  T here = cs * (p - qn), next = cs * (p - qc);  // to column n_i, to column n_next
+  T sdet = T(0);
+  if (MASS) {
+    sdet = flag_weight<T>(T(1), flag) * cross;
+    here = here + mass_o * sdet;
+    next = next + mass_o * sdet;
   }
-  out[pos(0)] = first + carry;  // the closing triangle's share (zero for an open fan)
+  const int lane = int(threadIdx.x) & 63;
+  const int from = (lane & ~15) + (i == 0 ? (k > 0 ? k - 1 : 0) : i - 1);
+  const T entry = here + __shfl(next, from, 64);
+  T sum = here + next, dsum = sdet;
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    sum = sum + __shfl_xor(sum, m, 64);
+    if (MASS) dsum = dsum + __shfl_xor(dsum, m, 64);
+  }
+  if (!slot) return;
+  T *out = vals + rec[1];
+  out[int((rec[19 + i / 8] >> (4 * (i % 8))) & 15u)] = entry;
   // stiffness rows sum to zero; the mass part is taken out of the sum and added on the diagonal
-  out[dpos] = MASS ? mass_d * dsum - (sum - T(2) * mass_o * dsum) : -sum;
+  if (i == 0) out[dpos] = MASS ? mass_d * dsum - (sum - T(2) * mass_o * dsum) : -sum;
 }
 
 struct RingLaunch {
@@ -275,7 +265,7 @@ static int launch_rings(const RingLaunch &L) {
   hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, L.stream);
   if (e != hipSuccess) return fail(TFEM_ERR_HIP, "ring kernel launch: %s", hipGetErrorString(e));
   if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours
-    const dim3 lgrid{unsigned((z[23] + kRingBlock - 1) / kRingBlock)};
+    const dim3 lgrid{unsigned((16 * z[23] + kRingBlock - 1) / kRingBlock)};  // sixteen lanes per row
     if (mass)
       hipLaunchKernelGGL((k_p1_long_rows<T, true>), lgrid, block, 0, L.stream, a.coords, a.plan, unsigned(z[22]),
                          int(z[23]), a.vals, a.stiff_w, a.mass_d, a.mass_o);

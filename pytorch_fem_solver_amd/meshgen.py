@@ -244,8 +244,11 @@ def morton_order(points: np.ndarray, bits: int = 16) -> np.ndarray:
     return np.argsort(key, kind="stable")
 
 
-def permute_mesh(mesh: dict, vertex_order=None, triangle_order=None) -> dict:
-    """Renumber vertices (``vertex_order[new] = old``) and/or reorder triangles."""
+def permute_mesh(mesh: dict, vertex_order=None, triangle_order=None, sort_edges=True) -> dict:
+    """Renumber vertices (``vertex_order[new] = old``) and/or reorder triangles.  With a vertex
+    renumbering the edge list is re-sorted by its (smaller, larger) new vertex ids (``sort_edges``):
+    the numbering of the edges -- the edge DoFs of a P2 basis -- then has the locality of the vertex
+    numbering instead of the generator's order."""
     out = {k: np.array(v, copy=True) for k, v in mesh.items()}
     if vertex_order is not None:
         vertex_order = np.asarray(vertex_order)
@@ -256,6 +259,12 @@ def permute_mesh(mesh: dict, vertex_order=None, triangle_order=None) -> dict:
         out["triangles"] = old_to_new[mesh["triangles"]].astype(np.int32)
         if "edges" in mesh:
             out["edges"] = old_to_new[mesh["edges"]].astype(np.int32)
+            if sort_edges:
+                lo, hi = out["edges"].min(axis=1).astype(np.int64), out["edges"].max(axis=1).astype(np.int64)
+                order = np.argsort(lo * vertex_order.shape[0] + hi, kind="stable")
+                out["edges"] = np.ascontiguousarray(out["edges"][order])
+                if "edge_markers" in mesh:
+                    out["edge_markers"] = np.ascontiguousarray(out["edge_markers"][order])
     if triangle_order is not None:
         triangle_order = np.asarray(triangle_order)
         out["triangles"] = np.ascontiguousarray(out["triangles"][triangle_order])
