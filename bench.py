@@ -58,6 +58,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | rings | tiles | atomic")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    p.add_argument("--no-interface-first", action="store_true",
+                   help="N > 1: one launch per step instead of interface tiles first + the rest")
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the short measurements of the other configurations (P2; Delaunay meshes)")
     p.add_argument("--delaunay-points", type=int, default=1_000_000,
@@ -329,9 +331,9 @@ def main():
             global_mesh, element_order[bounds[rank]:bounds[rank + 1]])
         total_elems = int(global_mesh["triangles"].shape[0])
     else:
-        # rank r owns the strip [r, r+1] x [0, 1]; identical jitter pattern per strip so that
-        # the shared boundary column coincides (boundary vertices are never displaced)
-        mesh_np = meshgen.structured_rectangle(n, n, float(rank), float(rank + 1), 0.0, 1.0, jitter=0.25, seed=0)
+        # rank r owns the strip [0, 1] x [r, r+1]; identical jitter pattern per strip so that
+        # the shared boundary row coincides (boundary vertices are never displaced)
+        mesh_np = meshgen.structured_rectangle(n, n, 0.0, 1.0, float(rank), float(rank + 1), jitter=0.25, seed=0)
         total_elems = int(mesh_np["triangles"].shape[0]) * world
     n_elems = mesh_np["triangles"].shape[0]
     n_verts = mesh_np["vertices"].shape[0]
@@ -348,10 +350,6 @@ def main():
     traced = forms.trace(load_form, basis, (), {})
     program = traced.coefficient.program()
     assert program is not None
-    engine.assemble_system(1.0, 0.0, source=program)  # builds the plans, first launch
-    torch.cuda.synchronize()
-    setup_ms = (time.perf_counter() - t_mesh) * 1e3  # symbolic phase + plans + device copies
-
     exchange = None
     if distributed and strong:
         exchange = parallel.InterfaceExchange.from_partition(
@@ -360,6 +358,17 @@ def main():
         del global_mesh
     elif distributed:
         exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine)
+    # interface tiles first: the ring plan lists the tiles that own a shared vertex
+    # first; a step is then two launches -- those tiles, whose rows go to the exchange at once,
+    # and the rest, which runs beside the all-reduce
+    interface_first = exchange is not None and not args.no_interface_first
+    if interface_first:
+        engine.set_priority_vertices(exchange.shared_vertices(n_verts))
+    engine.assemble_system(1.0, 0.0, source=program)  # builds the plans, first launch
+    torch.cuda.synchronize()
+    setup_ms = (time.perf_counter() - t_mesh) * 1e3  # symbolic phase + plans + device copies
+    if interface_first and engine.tile_range("priority")[1] in (0, engine.tile_range("all")[1]):
+        interface_first = False  # nothing (or everything) is shared: one launch
     # the interface all-reduce of step i runs on a side stream and overlaps the assembly
     # launch of step i+1 (steps are independent; every step's exchange completes inside the
     # timed region, which ends with a device-wide synchronise)
@@ -382,11 +391,14 @@ def main():
             return engine.assemble_system(1.0, 0.0, source=program)  # one fused launch: K and f
         slot = counter[0] % depth
         counter[0] += 1
-        vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot])
-        return vals, f, slot
-
-    def exchange_step(vals, f, slot):
-        exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
+        if interface_first:
+            vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="priority")
+            exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
+            engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="rest")
+        else:
+            vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot])
+            exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
+        return vals, f
 
     def barrier():
         if distributed:
@@ -401,16 +413,12 @@ def main():
     for k in range(device_warmup_steps):
         claim_pair()
         out = step()
-        if exchange is not None:
-            exchange_step(*out)
         if k % 10 == 9:
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         claim_pair()
         out = step()
-        if exchange is not None:
-            exchange_step(*out)
     barrier()
 
     # live launch duration: HIP events on the launch stream around every probe-th step
@@ -425,8 +433,6 @@ def main():
         out = step()
         if i in ends:
             ends[i].record()
-        if exchange is not None:
-            exchange_step(*out)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -485,6 +491,8 @@ def main():
                 "probe_every": probe,
                 "setup_ms": setup_ms,
                 "interface_buffer_bytes": exchange.nbytes if exchange is not None else 0,
+                "interface_tiles_first": (list(engine.tile_range("priority")) + [engine.tile_range("all")[1]]
+                                          if interface_first else None),
             },
             "roofline": {
                 "bound": "hbm",

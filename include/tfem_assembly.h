@@ -406,6 +406,25 @@ int tfem_p1_assemble_rings_source(const void *coords, int real_bytes, int64_t n_
                                   void *vals, int64_t nnz, const tfem_source_program *source,
                                   int64_t n_elems, void *fout, void *stream);
 
+/* Multi-GPU: the rows shared with other ranks first.  create_priority = create with
+ * vertex_priority_host (n_verts bytes, non-zero = flagged; NULL = none): the tiles that own a flagged
+ * vertex come first in the plan's tile list (*n_priority_tiles of them), the order inside both groups
+ * unchanged.  _range = tfem_p1_assemble_rings / _source (fq or source or neither) over the tiles
+ * [tile_first, tile_first + tile_count) only (tile_count < 0: to the end): the launch over the
+ * priority tiles completes every shared row, so their exchange can run beside the launch over the
+ * remaining tiles.  (In a plan with long rows those are written with the range that ends the list.) */
+int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                                   const double *coords_host, const int64_t *rowptr_host,
+                                   const int32_t *colind_host, int own_cap, int vert_cap,
+                                   const uint8_t *vertex_priority_host, void **plan_out,
+                                   int64_t *n_priority_tiles);
+int tfem_p1_assemble_rings_range(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                                 double alpha, double beta, const void *plan_device,
+                                 const int64_t *plan_layout_host, void *vals, int64_t nnz, const void *fq,
+                                 const tfem_source_program *source, int64_t n_elems, void *fout,
+                                 int64_t tile_first, int64_t tile_count, void *stream);
+
+
 /* ------------------------------------------------------------------------- *
  * The VPINN residual linear form, fused (DEVICE; P1 on one 2-D mesh):
  *   r_i = sum_T sum_q dx_q ( f(x_q) v_i(q) + flux_sign * grad v_i . g_q )

@@ -103,6 +103,16 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     ),
+    "tfem_ring_plan_create_priority": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+         c_void_p],
+    ),
+    "tfem_p1_assemble_rings_range": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int64,
+         c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p],
+    ),
     "tfem_ring_plan_sizes": (c_int, [c_void_p, c_void_p]),
     "tfem_ring_plan_pack": (c_int, [c_void_p, c_void_p]),
     "tfem_ring_plan_destroy": (None, [c_void_p]),

@@ -143,10 +143,11 @@ def unpack_plan(blob, layout):
 RING_DEFAULTS = {"own": 256, "vert": 448}
 
 
-def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap=None):
+def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap=None, priority=None):
     """Build the ring plan on the host (tfem_ring_plan_*): the row-form plan of the P1
     stiffness/mass kernel.  Raises NotImplementedError when the triangles around a vertex
-    do not form fans (non-manifold edge, duplicated element) or a row has > 16 entries."""
+    do not form fans (non-manifold edge, duplicated element) or a row has > 16 entries.
+    priority: per-vertex flags; the tiles owning a flagged vertex come first ("n_priority")."""
     lib = _native.load()
     env = lambda key, default: int(os.environ.get(key, default))  # noqa: E731
     own_cap = min(own_cap or env("TFEM_RING_OWN", RING_DEFAULTS["own"]), lib.tfem_ring_capacity(0))
@@ -156,11 +157,18 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
     rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
     colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
     handle = c_void_p()
+    n_priority = ctypes.c_int64(0)
+    if priority is not None:
+        priority = np.ascontiguousarray(np.asarray(priority).reshape(-1) != 0).view(np.uint8)
+        if priority.shape[0] != int(n_verts):
+            raise ValueError(f"priority: {priority.shape[0]} flags for {n_verts} vertices")
     _native.check(
-        lib.tfem_ring_plan_create(
+        lib.tfem_ring_plan_create_priority(
             c_void_p(conn.ctypes.data), 4, conn.shape[0], int(n_verts),
             c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
-            c_void_p(colind.ctypes.data), own_cap, vert_cap, ctypes.byref(handle),
+            c_void_p(colind.ctypes.data), own_cap, vert_cap,
+            c_void_p(priority.ctypes.data) if priority is not None else None, ctypes.byref(handle),
+            ctypes.byref(n_priority),
         )
     )
     try:
@@ -170,7 +178,9 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
         _native.check(lib.tfem_ring_plan_pack(handle, c_void_p(blob.ctypes.data)))
     finally:
         lib.tfem_ring_plan_destroy(handle)
-    return unpack_ring_plan(blob, layout)
+    plan = unpack_ring_plan(blob, layout)
+    plan["n_priority"] = int(n_priority.value)
+    return plan
 
 
 def unpack_ring_plan(blob, layout):
@@ -289,6 +299,7 @@ class AssemblyEngine:
         self._csr_host = None
         self._tiles = None
         self._rings = None
+        self._priority_vertices = None
         self._gather = None
         self._slots_host = None
         self._p2rows = None
@@ -533,6 +544,29 @@ class AssemblyEngine:
                             self._host_conn_dof.reshape(-1).cpu().long())
         )
 
+    def set_priority_vertices(self, flags):
+        """Multi-GPU: flag the vertices shared with other ranks BEFORE the first
+        assembly; the ring plan then lists the tiles owning them first, and
+        assemble_system(..., tiles="priority" / "rest") launches the two tile ranges, so the
+        exchange of the shared rows runs beside the launch over the rest."""
+        if self._rings is not None:
+            raise RuntimeError("set_priority_vertices: the ring plan is built already")
+        flags = np.asarray(flags.cpu() if torch.is_tensor(flags) else flags).reshape(-1) != 0
+        if flags.shape[0] != self.n_dofs:
+            raise ValueError(f"set_priority_vertices: {flags.shape[0]} flags for {self.n_dofs} DoFs")
+        self._priority_vertices = flags
+
+    def tile_range(self, which):
+        """(first, count) of the ring plan's tile list: "priority", "rest" or "all"."""
+        rings = self.ring_plan()
+        if rings is None:
+            raise NotImplementedError("tile ranges need the ring plan")
+        n, p = rings["n_tiles"], rings["n_priority"]
+        try:
+            return {"priority": (0, p), "rest": (p, n - p), "all": (0, n)}[which]
+        except KeyError:
+            raise ValueError(f"tiles: {which!r} is not 'priority', 'rest' or 'all'") from None
+
     def ring_plan(self):
         """Device copy of the ring plan (row form of the P1 stiffness/mass kernel), or None
         when this basis cannot use it (P2, fractures, fans that have no ring form)."""
@@ -545,6 +579,7 @@ class AssemblyEngine:
                     plan = ring_plan_host(
                         self._host_conn_dof.cpu().numpy(), self.n_dofs,
                         self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                        priority=self._priority_vertices,
                     )
                 except NotImplementedError:
                     plan = None
@@ -564,6 +599,8 @@ class AssemblyEngine:
                         # accumulation of the source-program launch only
                         "fq_ok": bool(plan["elems_staged"]) and int(plan["layout"][23]) == 0,
                         "rows_per_run": plan["rowstart"].size / n_runs,
+                        "n_tiles": plan["n_tiles"],
+                        "n_priority": plan["n_priority"],
                     }
             if self._rings is False and self.kernel == "rings":
                 raise NotImplementedError("the ring-plan kernel does not apply to this basis")
@@ -760,10 +797,12 @@ class AssemblyEngine:
                              f"entries on {self.device}")
         return given.view(-1)
 
-    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True, out=(None, None), source=None):
+    def _assemble_rings(self, alpha, beta, fq=None, want_matrix=True, out=(None, None), source=None,
+                        tiles=None):
         """One tfem_p1_assemble_rings launch: CSR values of alpha*stiffness + beta*mass and,
         with source values fq (E, Q) or a source program (evaluated in the launch), the load
-        vector (want_matrix=False: the vector alone)."""
+        vector (want_matrix=False: the vector alone).  tiles: (first, count) of the plan's tile
+        list -- the launch writes the rows those tiles own and leaves the others untouched."""
         d = self._inputs()
         rings = self.ring_plan()
         nnz = int(self.csr_structure()[1].shape[0])
@@ -776,7 +815,17 @@ class AssemblyEngine:
         if with_load:
             fout = self._output(out[1], self.n_dofs, "load vector")
         with torch.cuda.device(self.device):
-            if source is not None:
+            if tiles is not None:
+                _native.check(
+                    self.lib.tfem_p1_assemble_rings_range(
+                        _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
+                        float(alpha), float(beta), _native.ptr(rings["blob"]),
+                        c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
+                        _native.ptr(fq), ctypes.byref(source) if source is not None else None,
+                        self.n_elems, _native.ptr(fout), int(tiles[0]), int(tiles[1]), self._stream(),
+                    )
+                )
+            elif source is not None:
                 _native.check(
                     self.lib.tfem_p1_assemble_rings_source(
                         _native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order,
@@ -906,13 +955,24 @@ class AssemblyEngine:
             )
         return vals, fout
 
-    def assemble_system(self, alpha, beta, fq=None, out=None, source=None):
+    def assemble_system(self, alpha, beta, fq=None, out=None, source=None, tiles=None):
         """CSR values of alpha*stiffness + beta*mass AND the load vector of the source
         values fq (E, Q) or of the source program `source`: one fused launch on the ring and
         tile paths, two launches otherwise.  ``out=(vals, f)``: write into these preallocated
-        device buffers."""
+        device buffers.  ``tiles`` ("priority" / "rest" / "all", see set_priority_vertices):
+        only the rows owned by that range of the ring plan's tiles are written (into ``out``,
+        which is then required), the other entries are left as they are."""
         if (fq is None) == (source is None):
             raise ValueError("assemble_system: source values fq OR a source program")
+        if tiles is not None:
+            if out is None:
+                raise ValueError("assemble_system(tiles=...): the launch writes part of the rows, pass out=(vals, f)")
+            span = self.tile_range(tiles)
+            if source is not None and not self._rings_take_source():
+                raise NotImplementedError("tile ranges with a source program need the ring plan's element table")
+            if source is None and not self.ring_plan()["fq_ok"]:
+                raise NotImplementedError("tile ranges with source values need the staged element lists")
+            return self._assemble_rings(alpha, beta, fq, out=out, source=source, tiles=span)
         if source is not None:
             if self._rings_take_source():
                 return self._assemble_rings(alpha, beta, out=out or (None, None), source=source)

@@ -86,6 +86,7 @@ struct RingLaunch {
   int64_t n_elems = 0;
   void *fout = nullptr;
   const tfem_source_program *source = nullptr;  // load vector of this program instead of fq
+  int64_t tile_first = 0, tile_count = -1;       // tile range of the plan (-1: to the end)
   int blocks_per_cu = 0;  // > 0: cap on resident workgroups per CU (tuning)
   int flags = 0;          // > 0: ablation build (wrong results by design)
   unsigned long long *stamps = nullptr;
@@ -210,7 +211,13 @@ static int launch_rings(const RingLaunch &L) {
   a.off_rows = unsigned(z[9]);
   a.off_rowstart = unsigned(z[10]);
   a.off_gid = unsigned(z[11]);
-  a.n_tiles = int(z[0]);
+  const int64_t t_first = L.tile_first, t_count = L.tile_count < 0 ? z[0] - L.tile_first : L.tile_count;
+  if (t_first < 0 || t_count < 0 || t_first + t_count > z[0])
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "tile range [%lld, +%lld) outside the plan's %lld tiles",
+                (long long)t_first, (long long)t_count, (long long)z[0]);
+  if (t_count == 0) return TFEM_OK;
+  a.n_tiles = int(t_count);
+  a.tile_first = int(t_first);
   a.lds_vert = (int(z[3]) + 1) & ~1;
   // W = sum_q w_q/2 and M_ij = sum_q (w_q/2) l_i l_j, formed in T in quadrature order.  The
   // rules of element_tri.py:77-130 are symmetric, so M has one diagonal and one off-diagonal
@@ -253,7 +260,7 @@ static int launch_rings(const RingLaunch &L) {
     if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int deal = a.xcd_interleave > 0 ? a.xcd_interleave : 1;
-  const int per = int((z[0] + 8 * deal - 1) / (8 * deal)) * deal;
+  const int per = int((t_count + 8 * deal - 1) / (8 * deal)) * deal;
   // resident workgroups: what LDS and registers allow per CU, on every CU
   int per_cu = 0;
   hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRingBlock, lds);
@@ -264,7 +271,7 @@ static int launch_rings(const RingLaunch &L) {
   void *params[] = {&a};
   hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, L.stream);
   if (e != hipSuccess) return fail(TFEM_ERR_HIP, "ring kernel launch: %s", hipGetErrorString(e));
-  if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours
+  if (kmat && z[23] > 0 && t_first + t_count == z[0]) {  // the rows of the vertices with 8 .. 15 neighbours (with the last tiles)
     const dim3 lgrid{unsigned((16 * z[23] + kRingBlock - 1) / kRingBlock)};  // sixteen lanes per row
     if (mass)
       hipLaunchKernelGGL((k_p1_long_rows<T, true>), lgrid, block, 0, L.stream, a.coords, a.plan, unsigned(z[22]),
@@ -324,6 +331,27 @@ int tfem_p1_assemble_rings_source(const void *coords, int real_bytes, int64_t n_
   L.source = source;
   L.n_elems = n_elems;
   L.fout = fout;
+  if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
+  return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
+}
+
+int tfem_p1_assemble_rings_range(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
+                                 double alpha, double beta, const void *plan_device,
+                                 const int64_t *plan_layout_host, void *vals, int64_t nnz, const void *fq,
+                                 const tfem_source_program *source, int64_t n_elems, void *fout,
+                                 int64_t tile_first, int64_t tile_count, void *stream) {
+  using namespace tfem;
+  if (real_bytes != 4 && real_bytes != 8)
+    return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (!plan_layout_host) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_layout_host is NULL");
+  RingLaunch L{coords, quad_order, alpha, beta, static_cast<const unsigned char *>(plan_device),
+               plan_layout_host, n_verts, nnz, vals, static_cast<hipStream_t>(stream)};
+  L.fq = fq;
+  L.source = source;
+  L.n_elems = n_elems;
+  L.fout = fout;
+  L.tile_first = tile_first;
+  L.tile_count = tile_count;
   if (const char *v = std::getenv("TFEM_RINGS_PER_CU")) L.blocks_per_cu = std::atoi(v);
   return real_bytes == 8 ? launch_rings<double>(L) : launch_rings<float>(L);
 }

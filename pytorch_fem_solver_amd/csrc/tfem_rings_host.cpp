@@ -81,6 +81,7 @@ struct RingPlan {
   int64_t n_tiles = 0;
   bool chunked = false;           // every wave's 64 rows are 64 consecutive vertices
   bool long_mode = false;         // 4-dword records + long rows instead of 8-dword records
+  int64_t n_priority = 0;         // leading tiles that own a flagged vertex (tfem_ring_plan_create_priority)
 };
 
 namespace {
@@ -554,7 +555,20 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
 template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
-                bool chunk_mode, RingPlan &plan) {
+                bool chunk_mode, const uint8_t *priority, RingPlan &plan) {
+  // tiles that own a flagged vertex first, the order inside both groups unchanged (multi-GPU:
+  // the rows shared with other ranks are then complete after the first launch over a tile range)
+  auto priority_first = [&](std::vector<TileSpec> &tiles) {
+    plan.n_priority = 0;
+    if (!priority) return;
+    auto flagged = [&](const TileSpec &t) {
+      for (int32_t v : t.owned)
+        if (priority[size_t(v)]) return true;
+      return false;
+    };
+    const auto middle = std::stable_partition(tiles.begin(), tiles.end(), flagged);
+    plan.n_priority = int64_t(middle - tiles.begin());
+  };
   const bool timing = std::getenv("TFEM_PLAN_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -747,6 +761,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
           }
         }
       }, 64);
+      priority_first(specs);
       const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
       if (st != TFEM_OK) return st;
       if (int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
@@ -803,6 +818,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     ++tile;
   }
   lap("greedy tiling along the curve");
+  priority_first(specs);
   const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
   lap("emitting tiles");
   return st;
@@ -843,9 +859,11 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
 
 extern "C" {
 
-int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
-                          const double *coords_host, const int64_t *rowptr_host,
-                          const int32_t *colind_host, int own_cap, int vert_cap, void **plan_out) {
+int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                                   const double *coords_host, const int64_t *rowptr_host,
+                                   const int32_t *colind_host, int own_cap, int vert_cap,
+                                   const uint8_t *vertex_priority_host, void **plan_out,
+                                   int64_t *n_priority_tiles) {
   using namespace tfem;
   if (!plan_out) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_out is NULL");
   *plan_out = nullptr;
@@ -865,15 +883,23 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
   const int st =
       idx_bytes == 4
           ? build_rings(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, *plan)
+                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, *plan)
           : build_rings(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, *plan);
+                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, *plan);
   if (st != TFEM_OK) {
     delete plan;
     return st;
   }
   *plan_out = plan;
+  if (n_priority_tiles) *n_priority_tiles = plan->n_priority;
   return TFEM_OK;
+}
+
+int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                          const double *coords_host, const int64_t *rowptr_host,
+                          const int32_t *colind_host, int own_cap, int vert_cap, void **plan_out) {
+  return tfem_ring_plan_create_priority(conn_host, idx_bytes, n_elems, n_verts, coords_host, rowptr_host,
+                                        colind_host, own_cap, vert_cap, nullptr, plan_out, nullptr);
 }
 
 int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[24]) {

@@ -84,6 +84,14 @@ class InterfaceExchange:
         self.buffer = torch.zeros(self.n_matrix + self.n_vector, dtype=dtype, device=device)
         self.group = group
 
+    def shared_vertices(self, n_local):
+        """Flags (n_local,) of the local vertices whose rows take part in the exchange: what
+        AssemblyEngine.set_priority_vertices wants (every shared matrix entry (i, j) lies in the
+        row of a shared vertex i)."""
+        flags = np.zeros(int(n_local), dtype=bool)
+        flags[self.f_idx.cpu().numpy()] = True
+        return flags
+
     @property
     def nbytes(self):
         return self.buffer.numel() * self.buffer.element_size()
@@ -205,27 +213,28 @@ class InterfaceExchange:
     @classmethod
     def for_strips(cls, mesh, rank, world, engine, group=None):
         """Weak-scaling layout of bench.py: rank r holds the structured strip
-        [r, r+1] x [0, 1] (n x n cells, vertex id iy*(n+1)+ix); its right column is the
-        left column of rank r+1.  Interface k (between ranks k and k+1) carries, for the
-        n+1 column vertices, the diagonal entries, the 2n entries of the vertical edges
-        and the n+1 vector entries."""
+        [0, 1] x [r, r+1] (n x n cells, vertex id iy*(n+1)+ix); its top row is the bottom row
+        of rank r+1, so the shared vertices are two runs of consecutive ids (a handful of
+        the ring plan's tiles, contiguous pack / unpack).  Interface k (between ranks k and
+        k+1) carries, for the n+1 row vertices, the diagonal entries, the 2n entries of the
+        horizontal edges and the n+1 vector entries."""
         n = int(round(np.sqrt(mesh["triangles"].shape[0] // 2)))
         nvx = n + 1
         csr = engine.csr_structure()
         rowptr, colind = csr[0].cpu().numpy(), csr[1].cpu().numpy()
-        iy = np.arange(nvx, dtype=np.int64)
+        ix = np.arange(nvx, dtype=np.int64)
         per_k = nvx + 2 * n
         k_idx, k_pos, f_idx, f_pos = [], [], [], []
-        for interface, ix in ((rank - 1, 0), (rank, n)):
+        for interface, iy in ((rank - 1, 0), (rank, n)):
             if interface < 0 or interface >= world - 1:
                 continue
-            col = iy * nvx + ix
-            rows = np.concatenate([col, col[:-1], col[1:]])
-            cols = np.concatenate([col, col[1:], col[:-1]])
+            line = iy * nvx + ix
+            rows = np.concatenate([line, line[:-1], line[1:]])
+            cols = np.concatenate([line, line[1:], line[:-1]])
             k_idx.append(_csr_positions(rowptr, colind, rows, cols))
             k_pos.append(interface * per_k + np.arange(per_k))
-            f_idx.append(col)
-            f_pos.append(interface * nvx + iy)
+            f_idx.append(line)
+            f_pos.append(interface * nvx + ix)
         cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)  # noqa: E731
         return cls(cat(k_idx), cat(k_pos), cat(f_idx), cat(f_pos), max(world - 1, 0) * per_k,
                    max(world - 1, 0) * nvx, engine.device, engine.dtype, group)

@@ -30,13 +30,14 @@ def decode_rows(rows, slots):
 
 
 def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=None, lamw=None,
-                  conn=None, source=None, lam=None):
+                  conn=None, source=None, lam=None, tiles=None):
     """Returns (vals, writes, covered[, f]): CSR values of stiff_w-weighted stiffness + mass,
     how often every CSR entry was written, the number of rows covered and -- with source
     values fq (E, Q) and the table lamw (3, Q) = l_i(q) w_q / 2 -- the load vector.
     conn: the connectivity, to check the tiles' element vertex tables against.  source = (ops,
     consts) with lam (3, Q) = l_i(q): the source values are not taken from fq but computed per
-    tile from the tile-local coordinates through tile_tverts, as the SRC kernels do."""
+    tile from the tile-local coordinates through tile_tverts, as the SRC kernels do.
+    tiles = (first, count): that range of the tile list only (tfem_p1_assemble_rings_range)."""
     from oracle.assembly_oracle import source_program_eval
 
     slots, words = plan["slots"], plan["words"]
@@ -49,6 +50,8 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
     fvec = np.full(coords.shape[0], np.nan) if (fq is not None or source is not None) else None
     ewords = (12 * slots + 31) // 32  # packed 12-bit slot codes
     row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
+    if tiles is not None:
+        desc = desc[tiles[0]:tiles[0] + tiles[1]]
     for d in desc:
         vert_off, n_vert, row_off, ws0, ws1, ws2, ws3, n_own = (int(x) for x in d[:8])
         wave_start = [ws0, ws1, ws2, ws3, n_own]

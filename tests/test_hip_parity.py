@@ -1019,6 +1019,104 @@ def test_partitioned_assembly_with_interface_sum_equals_the_global_operator(orde
         assert 0 < ex.n_vector < n_global
 
 
+@pytest.mark.parametrize("mesh_kind", ["strip", "partition"])
+@pytest.mark.parametrize("load_kind", ["program", "values", "matrix_only"])
+def test_interface_tiles_first_two_range_launches_equal_one_launch(mesh_kind, load_kind):
+    """with the shared vertices flagged the ring plan lists their tiles first and
+    tfem_p1_assemble_rings_range launches the two tile ranges.  The first launch completes every
+    shared row (what the exchange packs), the two together reproduce the single launch bit for
+    bit, and the exchange may pack / unpack on a side stream while the second range runs."""
+    from pytorch_fem_solver_amd import meshgen, parallel
+    from pytorch_fem_solver_amd.basis import forms
+
+    if mesh_kind == "strip":  # bench.py's weak-scaling strip, middle rank of three
+        n = 150
+        mesh_np = meshgen.structured_rectangle(n, n, 0.0, 1.0, 1.0, 2.0, jitter=0.25, seed=0)
+        l2g = None
+    else:  # bench.py --scaling strong: one of four Morton ranges of a Delaunay mesh
+        whole = meshgen.delaunay_square(200000, seed=2)
+        whole = meshgen.permute_mesh(whole, vertex_order=meshgen.morton_order(whole["vertices"]))
+        element_order, bounds = parallel.partition_elements(whole["vertices"], whole["triangles"], 4, "morton")
+        mesh_np, l2g = parallel.extract_shard(whole, element_order[bounds[1]:bounds[2]])
+    nv = mesh_np["vertices"].shape[0]
+
+    def engine_of():
+        basis = tf().Basis(tf().MeshTri(triangulation=mesh_np), tf().ElementTri(1, 3))
+        return basis, basis._engine
+
+    basis, eng = engine_of()
+    csr = eng.csr_structure()
+    rowptr, colind = csr[0].cpu().numpy(), csr[1].cpu().numpy()
+    if mesh_kind == "strip":
+        ex = parallel.InterfaceExchange.for_strips(mesh_np, 1, 3, eng)
+    else:
+        ex = parallel.InterfaceExchange.from_partition(
+            whole, element_order, bounds, 1, rowptr, colind, l2g, torch.device("cuda"), torch.float64)
+    flags = ex.shared_vertices(nv)
+    assert 0 < flags.sum() < nv
+    program = forms.trace(load, basis, (), {}).coefficient.program()
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    fq = rhs(x, y).reshape(-1, eng.n_quad).contiguous()
+    kw = {"program": dict(source=program), "values": dict(fq=fq), "matrix_only": {}}[load_kind]
+
+    def one_launch(e, out=None, tiles=None):
+        if load_kind == "matrix_only":
+            span = e.tile_range(tiles) if tiles else None
+            vals = e._assemble_rings(1.0, 0.5, out=(out[0] if out else None, None), tiles=span)
+            return vals, None
+        return e.assemble_system(1.0, 0.5, out=out, tiles=tiles, **kw)
+
+    if load_kind == "values" and not eng.ring_plan()["fq_ok"]:
+        pytest.skip("this plan takes source programs only")
+    want_v, want_f = one_launch(eng)
+    # the same mesh with the interface flagged (flags go in before the plan is built)
+    basis2, eng2 = engine_of()
+    eng2.set_priority_vertices(flags)
+    first, n_pri = eng2.tile_range("priority")
+    rest_first, n_rest = eng2.tile_range("rest")
+    n_all = eng2.tile_range("all")[1]
+    assert first == 0 and rest_first == n_pri and n_pri + n_rest == n_all
+    assert 0 < n_pri < (n_all / 4 if mesh_kind == "strip" else n_all)
+    with pytest.raises(RuntimeError):
+        eng2.set_priority_vertices(flags)  # the plan exists now
+    nnz = colind.shape[0]
+    out = (torch.full((nnz,), float("nan")), torch.full((nv,), float("nan")))
+    one_launch(eng2, out=out, tiles="priority")
+    torch.cuda.synchronize()
+    row_of = np.repeat(np.arange(nv), np.diff(rowptr))
+    shared_entries = torch.from_numpy(flags[row_of]).cuda()
+    assert torch.equal(out[0][shared_entries], want_v.view(-1)[shared_entries])  # shared rows complete
+    assert torch.isnan(out[0]).any()  # and the other rows still untouched
+    # the load vector of a source program is summed with LDS atomics inside a tile (order of
+    # arrival): equal to rounding, not bit for bit; the vector of source values is in row form
+    same_f = (lambda a, b: scaled_error(a.cpu(), b.cpu()) <= 1e-15) if load_kind == "program" else torch.equal
+    if want_f is not None:
+        on = torch.from_numpy(flags).cuda()
+        assert same_f(out[1][on], want_f.view(-1)[on])
+    # exchange of the shared rows on a side stream, beside the launch over the rest (one rank:
+    # the all-reduce is the identity; pack and unpack still read and write the shared entries)
+    side = torch.cuda.Stream()
+    ready = torch.cuda.Event()
+    ready.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        ex.pack(out[0], out[1] if want_f is not None else None)
+        ex.unpack(out[0], out[1] if want_f is not None else None)
+    one_launch(eng2, out=out, tiles="rest")
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], want_v.view(-1))
+    if want_f is not None:
+        assert same_f(out[1], want_f.view(-1))
+    # argument checks of the range entry
+    with pytest.raises(ValueError):
+        eng2.assemble_system(1.0, 0.5, source=program, tiles="priority")  # needs out=
+    with pytest.raises(ValueError):
+        eng2.assemble_system(1.0, 0.5, source=program, out=out, tiles="some")
+    with pytest.raises(ValueError):
+        eng2._assemble_rings(1.0, 0.5, out=(out[0], None), tiles=(n_all - 1, 2))
+
+
 def test_assembly_launches_can_be_captured_in_a_hip_graph():
     """Launch-bound callers (small meshes, thousands of steps) capture the launch once and
     replay it: the C ABI enqueues on the caller's stream only, so torch.cuda.graph records it.

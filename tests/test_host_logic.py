@@ -248,6 +248,48 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form, monkeypatch):
     assert scaled_error(fsrc, want_f) <= 1e-13
 
 
+@pytest.mark.parametrize("kind", ["structured", "delaunay"])
+def test_ring_plan_lists_the_tiles_of_flagged_vertices_first(kind):
+    """tfem_ring_plan_create_priority (multi-GPU): same tiles as without flags, the
+    ones owning a flagged vertex first; the range launches partition the rows."""
+    from pytorch_fem_solver_amd.basis.engine import ring_plan_host, symbolic_host
+
+    mesh = _ring_case(kind)
+    nv = mesh["vertices"].shape[0]
+    rowptr, colind, slots = symbolic_host(mesh["triangles"], nv)
+    flags = np.zeros(nv, dtype=bool)
+    flags[np.random.default_rng(5).choice(nv, 7, replace=False)] = True  # a few vertices anywhere
+    flags[nv - 40:nv - 20] = True  # and a run of consecutive ids (a strip's shared row)
+    caps = dict(own_cap=64, vert_cap=160)
+    plain = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, **caps)
+    plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=flags, **caps)
+    n_pri, n_tiles = plan["n_priority"], plan["n_tiles"]
+    assert plain["n_priority"] == 0 and n_tiles == plain["n_tiles"] and 0 < n_pri < n_tiles
+
+    def owned(p):
+        d = p["desc"].reshape(-1, 20)
+        return [tuple(p["vert_gid"][int(t[0]):int(t[0]) + int(t[7])]) for t in d]
+
+    with_flags, without = owned(plan), owned(plain)
+    assert sorted(with_flags) == sorted(without)
+    has = [bool(flags[list(t)].any()) for t in with_flags]
+    assert all(has[:n_pri]) and not any(has[n_pri:])
+    # stable: both groups keep the order of the plan without flags
+    assert [t for t in without if flags[list(t)].any()] == with_flags[:n_pri]
+    assert [t for t in without if not flags[list(t)].any()] == with_flags[n_pri:]
+    nnz = colind.shape[0]
+    full, writes, covered = run_ring_plan(plan, mesh["vertices"], nnz)[:3]
+    assert covered == nv and (writes == 1).all()
+    first, w_first, c_first = run_ring_plan(plan, mesh["vertices"], nnz, tiles=(0, n_pri))[:3]
+    rest, w_rest, c_rest = run_ring_plan(plan, mesh["vertices"], nnz, tiles=(n_pri, n_tiles - n_pri))[:3]
+    assert c_first + c_rest == nv and ((w_first + w_rest) == 1).all()
+    row_of = np.repeat(np.arange(nv), np.diff(rowptr))
+    assert (w_first[flags[row_of]] == 1).all()  # every flagged row is complete after the first range
+    assert np.array_equal(np.where(w_first == 1, first, rest), full)
+    with pytest.raises(ValueError):
+        ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=flags[:-1])
+
+
 def test_ring_plan_open_fans_and_isolated_vertices():
     """Two fans meeting in one vertex (a bow tie) chain as two open fans; a vertex without
     elements owns an empty row."""

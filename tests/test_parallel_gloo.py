@@ -84,22 +84,22 @@ def _worker_strips(rank, world, port, results):
         from pytorch_fem_solver_amd import meshgen, parallel
 
         n = 6
-        strips = [meshgen.structured_rectangle(n, n, float(r), float(r + 1), 0.0, 1.0, jitter=0.25, seed=0)
+        strips = [meshgen.structured_rectangle(n, n, 0.0, 1.0, float(r), float(r + 1), jitter=0.25, seed=0)
                   for r in range(world)]
         systems = [_local_system(s) for s in strips]
         rowptr, colind, vals, f = systems[rank]
         ex = parallel.InterfaceExchange.for_strips(strips[rank], rank, world, _FakeEngine(rowptr, colind))
         tv, tf_ = torch.from_numpy(vals.copy()), torch.from_numpy(f.copy())
         ex.reduce(tv, tf_)
-        # expected: own values + the neighbour's values on the shared column
+        # expected: own values + the neighbour's values on the shared row of vertices
         nvx = n + 1
         want_v, want_f = vals.copy(), f.copy()
         dense = [orc.csr_to_dense(s[0], s[1], s[2], nvx * nvx) for s in systems]
-        for other, my_ix, their_ix in ((rank - 1, 0, n), (rank + 1, n, 0)):
+        for other, my_iy, their_iy in ((rank - 1, 0, n), (rank + 1, n, 0)):
             if other < 0 or other >= world:
                 continue
-            mine_col = np.arange(nvx) * nvx + my_ix
-            theirs_col = np.arange(nvx) * nvx + their_ix
+            mine_col = my_iy * nvx + np.arange(nvx)
+            theirs_col = their_iy * nvx + np.arange(nvx)
             want_f[mine_col] += systems[other][3][theirs_col]
             rows = np.repeat(np.arange(nvx * nvx), np.diff(rowptr))
             pos_of = {v: i for i, v in enumerate(mine_col)}
