@@ -221,7 +221,7 @@ def fracture_rectangle(m: int, jitter: float = 0.0, seed: int = 0) -> dict:
     nv = mesh["vertices"].shape[0]
     rest = np.setdiff1d(np.arange(nv), np.array(first), assume_unique=False)
     new_to_old = np.concatenate([np.array(first), rest])
-    return permute_mesh(mesh, vertex_order=new_to_old)
+    return permute_mesh(mesh, vertex_order=new_to_old, sort_edges=False)  # edge order of the committed fixtures
 
 
 def morton_order(points: np.ndarray, bits: int = 16) -> np.ndarray:
