@@ -571,6 +571,19 @@ def main():
             del fq
             line["roofline"]["sources"] = sources
         if world == 1 and not args.no_other_configs:
+            # what a caller who re-meshes pays per mesh: the same set-up on a second mesh of the
+            # family (other jitter seed) in this process -- setup_ms above also holds what a
+            # process pays once (torch loading its device kernels on first use, the library)
+            del engine, basis, mesh
+            other = meshgen.unit_square(n, 0.25, 1)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            mesh2 = tf.MeshTri(triangulation=other)
+            basis2 = tf.Basis(mesh2, tf.ElementTri(polynomial_order=1, integration_order=args.order))
+            basis2._engine.assemble_system(1.0, 0.0, source=program)
+            torch.cuda.synchronize()
+            line["config"]["setup_remesh_ms"] = (time.perf_counter() - t2) * 1e3
+            del basis2, mesh2, other
             line["other_configs"] = {"C3_p2_stiffness_1e6": p2_config3()}
             line["other_configs"].update(delaunay_configs(args.delaunay_points, args.order))
         if world == 1 and not args.no_cpu_baseline:  # rank 0 at N = 1 only

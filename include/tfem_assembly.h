@@ -418,6 +418,13 @@ int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t
                                    const int32_t *colind_host, int own_cap, int vert_cap,
                                    const uint8_t *vertex_priority_host, void **plan_out,
                                    int64_t *n_priority_tiles);
+/* The same plan from a CSR pattern handle (tfem_csr_pattern_create of the P1 connectivity, still
+ * alive, with the colind tfem_csr_pattern_export wrote): reuses the handle's connectivity, row
+ * pointers and vertex -> elements incidence instead of building the incidence again (the lists of
+ * the handle are sorted in place).  Same plan bytes as tfem_ring_plan_create_priority. */
+int tfem_ring_plan_create_from_pattern(void *pattern, const double *coords_host, const int32_t *colind_host,
+                                       int own_cap, int vert_cap, const uint8_t *vertex_priority_host,
+                                       void **plan_out, int64_t *n_priority_tiles);
 int tfem_p1_assemble_rings_range(const void *coords, int real_bytes, int64_t n_verts, int quad_order,
                                  double alpha, double beta, const void *plan_device,
                                  const int64_t *plan_layout_host, void *vals, int64_t nnz, const void *fq,

@@ -108,6 +108,9 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
          c_void_p],
     ),
+    "tfem_ring_plan_create_from_pattern": (
+        c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    ),
     "tfem_p1_assemble_rings_range": (
         c_int,
         [c_void_p, c_int, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int64,

@@ -34,9 +34,25 @@ def _compute_device(home: torch.device) -> torch.device:
     )
 
 
-def pattern_host(conn_dof, n_dofs):
+class PatternHandle:
+    """A live tfem_csr_pattern handle (with the connectivity it points into), for the plan
+    builder that starts from its incidence; released explicitly or with the object."""
+
+    def __init__(self, handle, conn):
+        self.handle, self.conn = handle, conn
+
+    def release(self):
+        if self.handle is not None:
+            _native.load().tfem_csr_pattern_destroy(self.handle)
+            self.handle = self.conn = None
+
+    __del__ = release
+
+
+def pattern_host(conn_dof, n_dofs, keep=False):
     """CSR pattern of the operator (replaces the index tensors of basis.py:64-85): rowptr int64
-    (N+1), colind int32 (nnz), numpy in, numpy out; one pass of the multi-threaded host builder."""
+    (N+1), colind int32 (nnz), numpy in, numpy out; one pass of the multi-threaded host builder.
+    keep=True: also the live PatternHandle (third value) for ring_plan_host(pattern=...)."""
     lib = _native.load()
     conn = np.ascontiguousarray(np.asarray(conn_dof).astype(np.int32, copy=False))
     conn = conn.reshape(-1, conn.shape[-1])
@@ -44,12 +60,17 @@ def pattern_host(conn_dof, n_dofs):
     handle, nnz = c_void_p(), ctypes.c_int64(0)
     _native.check(lib.tfem_csr_pattern_create(c_void_p(conn.ctypes.data), 4, e, n, int(n_dofs),
                                               ctypes.byref(handle), ctypes.byref(nnz)))
+    keeper = PatternHandle(handle, conn)
     try:
         rowptr = np.empty(int(n_dofs) + 1, dtype=np.int64)
         colind = np.empty(max(nnz.value, 1), dtype=np.int32)
         _native.check(lib.tfem_csr_pattern_export(handle, c_void_p(rowptr.ctypes.data), c_void_p(colind.ctypes.data)))
-    finally:
-        lib.tfem_csr_pattern_destroy(handle)
+    except BaseException:
+        keeper.release()
+        raise
+    if keep:
+        return rowptr, colind[: nnz.value], keeper
+    keeper.release()
     return rowptr, colind[: nnz.value]
 
 
@@ -94,7 +115,7 @@ def tile_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, acc_cap=
     elem_cap = min(elem_cap or 1 << 30, lib.tfem_tile_capacity(0))
     vert_cap = min(vert_cap, lib.tfem_tile_capacity(1))
     own_cap = min(own_cap, lib.tfem_tile_capacity(2))
-    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32)).reshape(-1, 3)
+    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32, copy=False)).reshape(-1, 3)
     coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
     rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
     colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
@@ -143,16 +164,19 @@ def unpack_plan(blob, layout):
 RING_DEFAULTS = {"own": 256, "vert": 448}
 
 
-def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap=None, priority=None):
+def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap=None, priority=None,
+                   pattern=None):
     """Build the ring plan on the host (tfem_ring_plan_*): the row-form plan of the P1
     stiffness/mass kernel.  Raises NotImplementedError when the triangles around a vertex
     do not form fans (non-manifold edge, duplicated element) or a row has > 16 entries.
-    priority: per-vertex flags; the tiles owning a flagged vertex come first ("n_priority")."""
+    priority: per-vertex flags; the tiles owning a flagged vertex come first ("n_priority").
+    pattern: the live PatternHandle of this connectivity (pattern_host(keep=True)): the builder
+    takes the vertex -> elements incidence from it instead of building it again."""
     lib = _native.load()
     env = lambda key, default: int(os.environ.get(key, default))  # noqa: E731
     own_cap = min(own_cap or env("TFEM_RING_OWN", RING_DEFAULTS["own"]), lib.tfem_ring_capacity(0))
     vert_cap = min(vert_cap or env("TFEM_RING_VERT", RING_DEFAULTS["vert"]), lib.tfem_ring_capacity(1))
-    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32)).reshape(-1, 3)
+    conn = np.ascontiguousarray(np.asarray(conn).astype(np.int32, copy=False)).reshape(-1, 3)
     coords = np.ascontiguousarray(np.asarray(coords, dtype=np.float64)).reshape(-1, 2)
     rowptr = np.ascontiguousarray(np.asarray(rowptr, dtype=np.int64))
     colind = np.ascontiguousarray(np.asarray(colind, dtype=np.int32))
@@ -162,15 +186,23 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
         priority = np.ascontiguousarray(np.asarray(priority).reshape(-1) != 0).view(np.uint8)
         if priority.shape[0] != int(n_verts):
             raise ValueError(f"priority: {priority.shape[0]} flags for {n_verts} vertices")
-    _native.check(
-        lib.tfem_ring_plan_create_priority(
-            c_void_p(conn.ctypes.data), 4, conn.shape[0], int(n_verts),
-            c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
-            c_void_p(colind.ctypes.data), own_cap, vert_cap,
-            c_void_p(priority.ctypes.data) if priority is not None else None, ctypes.byref(handle),
-            ctypes.byref(n_priority),
+    flags = c_void_p(priority.ctypes.data) if priority is not None else None
+    if pattern is not None and pattern.handle is not None:
+        _native.check(
+            lib.tfem_ring_plan_create_from_pattern(
+                pattern.handle, c_void_p(coords.ctypes.data), c_void_p(colind.ctypes.data), own_cap,
+                vert_cap, flags, ctypes.byref(handle), ctypes.byref(n_priority),
+            )
         )
-    )
+    else:
+        _native.check(
+            lib.tfem_ring_plan_create_priority(
+                c_void_p(conn.ctypes.data), 4, conn.shape[0], int(n_verts),
+                c_void_p(coords.ctypes.data), c_void_p(rowptr.ctypes.data),
+                c_void_p(colind.ctypes.data), own_cap, vert_cap, flags, ctypes.byref(handle),
+                ctypes.byref(n_priority),
+            )
+        )
     try:
         layout = np.zeros(24, dtype=np.int64)
         _native.check(lib.tfem_ring_plan_sizes(handle, c_void_p(layout.ctypes.data)))
@@ -303,6 +335,10 @@ class AssemblyEngine:
         self._gather = None
         self._slots_host = None
         self._p2rows = None
+        self._pattern = None    # live CSR pattern handle between csr_structure() and ring_plan()
+        self._conn_np = None    # DoF connectivity, int32 on the host (one copy for every builder)
+        self._coords_np = None  # coordinates, float64 on the host
+        self._same_conn = None
         self._edge_cells_checked = None  # (data_ptr, rows) of the last validated edge -> cells table
         #: "auto" (the best plan the mesh allows), "rings", "tiles", "rows" (P2 row kernels),
         #: "gather" (element blocks / vectors + gather, no plan) or "atomic" (one-pass scatter)
@@ -483,13 +519,43 @@ class AssemblyEngine:
         return tensor.to(self.home)
 
     # ------------------------------------------------------------------ symbolic phase
+    def _conn_host_np(self):
+        """The DoF connectivity as one contiguous int32 host array (narrowed where it lives:
+        a third of the bytes of an int64 device tensor cross the bus)."""
+        if self._conn_np is None:
+            conn = self._host_conn_dof
+            if conn.numel() and int(conn.max()) >= 2**31:
+                raise ValueError("DoF ids beyond the int32 range of the kernels")
+            self._conn_np = np.ascontiguousarray(conn.to(torch.int32).cpu().numpy())
+        return self._conn_np
+
+    def _coords_host_np(self):
+        if self._coords_np is None:
+            self._coords_np = np.ascontiguousarray(self._host_coords.detach().cpu().double().numpy())
+        return self._coords_np
+
+    def _geometry_is_dof_connectivity(self):
+        """P1 on one mesh: the vertex connectivity IS the DoF connectivity (compared where the
+        tensors live, once)."""
+        if self._same_conn is None:
+            a, b = self._host_conn_geo.reshape(-1), self._host_conn_dof.reshape(-1)
+            if a.shape != b.shape:
+                self._same_conn = False
+            elif a.data_ptr() == b.data_ptr() and a.dtype == b.dtype:
+                self._same_conn = True
+            else:
+                b = b.to(a.device)
+                self._same_conn = bool(torch.equal(a, b) if a.dtype == b.dtype else torch.equal(a.long(), b.long()))
+        return self._same_conn
+
     def csr_structure(self):
         """(rowptr int64, colind int32, slots) on the compute device.  `slots` (int32 (E,n,n), the
         CSR position of every element entry) is built on first use: only the scatter / gather
         paths read it."""
         if self._csr is None:
-            conn = self._host_conn_dof.cpu().numpy()
-            rowptr, colind = pattern_host(conn, self.n_dofs)
+            keep = self.kernel in ("auto", "rings") and self._p1_plan_eligible()  # the ring plan starts from it
+            rowptr, colind, *kept = pattern_host(self._conn_host_np(), self.n_dofs, keep=keep)
+            self._pattern = kept[0] if kept else None
             self._csr_host = (rowptr, colind)
             dev = self.device
             self._csr = _LazyTriple(torch.from_numpy(rowptr).to(dev), torch.from_numpy(colind).to(dev), self._device_slots)
@@ -499,7 +565,7 @@ class AssemblyEngine:
         if self._slots_host is None:
             self.csr_structure()
             rowptr, colind = self._csr_host
-            self._slots_host = slots_host(self._host_conn_dof.cpu().numpy(), self.n_dofs, rowptr, colind)
+            self._slots_host = slots_host(self._conn_host_np(), self.n_dofs, rowptr, colind)
         return self._slots_host
 
     def _device_slots(self):
@@ -513,16 +579,14 @@ class AssemblyEngine:
             eligible = (
                 self.kernel in ("auto", "tiles", "rings") and self.poly_order == 1
                 and self.n_fractures == 0 and self._host_conn_geo.dim() == 2
-                and torch.equal(self._host_conn_geo.reshape(-1).cpu().long(),
-                                self._host_conn_dof.reshape(-1).cpu().long())
+                and self._geometry_is_dof_connectivity()
             )
             if eligible:
                 self.csr_structure()
                 rowptr, colind = self._csr_host
                 try:
                     plan = tile_plan_host(
-                        self._host_conn_dof.cpu().numpy(), self.n_dofs,
-                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                        self._conn_host_np(), self.n_dofs, self._coords_host_np(), rowptr, colind,
                     )
                 except NotImplementedError:
                     plan = None
@@ -540,8 +604,7 @@ class AssemblyEngine:
         return (
             self.kernel != "atomic" and self.poly_order == 1 and self.n_fractures == 0
             and self._host_conn_geo.dim() == 2
-            and torch.equal(self._host_conn_geo.reshape(-1).cpu().long(),
-                            self._host_conn_dof.reshape(-1).cpu().long())
+            and self._geometry_is_dof_connectivity()
         )
 
     def set_priority_vertices(self, flags):
@@ -577,12 +640,15 @@ class AssemblyEngine:
                 rowptr, colind = self._csr_host
                 try:
                     plan = ring_plan_host(
-                        self._host_conn_dof.cpu().numpy(), self.n_dofs,
-                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
-                        priority=self._priority_vertices,
+                        self._conn_host_np(), self.n_dofs, self._coords_host_np(), rowptr, colind,
+                        priority=self._priority_vertices, pattern=self._pattern,
                     )
                 except NotImplementedError:
                     plan = None
+                finally:
+                    if self._pattern is not None:
+                        self._pattern.release()
+                        self._pattern = None
                 if plan is not None:
                     # rows per output run (group of rows contiguous in the CSR array): the ring
                     # kernel streams a wave's rows out run by run, so a numbering without
@@ -616,8 +682,8 @@ class AssemblyEngine:
                 rowptr, colind = self._csr_host
                 try:
                     plan = p2_plan_host(
-                        self._host_conn_dof.cpu().numpy(), self.coords_per_mesh, self.n_dofs,
-                        self._host_coords.detach().cpu().double().numpy(), rowptr, colind,
+                        self._conn_host_np(), self.coords_per_mesh, self.n_dofs, self._coords_host_np(),
+                        rowptr, colind,
                     )
                 except NotImplementedError:
                     plan = None
@@ -661,7 +727,7 @@ class AssemblyEngine:
         """The same for vectors: for every DoF the element-vector entries that add to it
         (tfem_csr_gather_map applied to the DoF connectivity)."""
         if getattr(self, "_gather_lin", None) is None:
-            conn = np.ascontiguousarray(self._host_conn_dof.cpu().numpy().astype(np.int32))
+            conn = self._conn_host_np()
             gptr = np.zeros(self.n_dofs + 1, dtype=np.int64)
             gsrc = np.zeros(max(conn.size, 1), dtype=np.int32)
             _native.check(self.lib.tfem_csr_gather_map(

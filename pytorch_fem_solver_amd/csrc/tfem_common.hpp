@@ -29,4 +29,18 @@ struct TriTables {
 bool triangle_rule(int quad_order, int *nq, double nodes[kMaxQuad][2], double weights[kMaxQuad]);
 bool build_tri_tables(int quad_order, int real_bytes, TriTables *out);
 
+// What a CSR pattern handle (tfem_csr_pattern_create) holds, for the plan builders that start
+// from it: the DoF -> elements incidence (lists in arrival order; a builder may sort them in
+// place), the row pointers and the caller's connectivity.
+struct PatternView {
+  const void *conn;
+  int idx_bytes;
+  int n_local;
+  int64_t n_elems, n_dofs, nnz;
+  const int64_t *inc_ptr;
+  int32_t *inc;
+  const int64_t *rowptr;
+};
+bool pattern_view(void *pattern_handle, PatternView *out);
+
 }  // namespace tfem

@@ -310,6 +310,15 @@ int check_symbolic_args(const void *conn, int idx_bytes, int64_t n_elems, int n_
 }
 
 }  // namespace
+
+bool pattern_view(void *pattern_handle, PatternView *out) {
+  if (!pattern_handle || !out) return false;
+  auto *h = static_cast<PatternHandle *>(pattern_handle);
+  *out = PatternView{h->conn, h->idx_bytes, h->p.n, h->p.n_elems, h->p.n_dofs, h->p.nnz,
+                     h->p.inc_ptr.data(), h->p.inc.get(), h->p.rowptr.data()};
+  return true;
+}
+
 }  // namespace tfem
 
 extern "C" {

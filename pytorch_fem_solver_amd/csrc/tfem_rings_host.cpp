@@ -555,7 +555,8 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
 template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
-                bool chunk_mode, const uint8_t *priority, RingPlan &plan) {
+                bool chunk_mode, const uint8_t *priority, const int64_t *inc_ptr, int32_t *inc,
+                RingPlan &plan) {
   // tiles that own a flagged vertex first, the order inside both groups unchanged (multi-GPU:
   // the rows shared with other ranks are then complete after the first launch over a tile range)
   auto priority_first = [&](std::vector<TileSpec> &tiles) {
@@ -606,27 +607,33 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   // ---- vertex -> incident elements (ascending per vertex) ----------------------------------
   // bucket sizes and filling with relaxed atomic counters, then every vertex's short list sorted:
   // the result does not depend on the thread count
-  std::vector<int64_t> adj_ptr(size_t(n_verts) + 1, 0);
-  {
-    std::vector<int64_t> count(size_t(n_verts) + 1, 0);
-    parallel_for(3 * n_elems, [&](int64_t b, int64_t e, int) {
-      for (int64_t k = b; k < e; ++k) __atomic_fetch_add(&count[size_t(conn[k]) + 1], int64_t(1), __ATOMIC_RELAXED);
-    }, 1 << 16);
-    std::partial_sum(count.begin(), count.end(), adj_ptr.begin());
-  }
-  std::unique_ptr<int32_t[]> adj_store(new int32_t[size_t(std::max<int64_t>(3 * n_elems, 1))]);
-  int32_t *adj_data = adj_store.get();
-  {
-    std::vector<int64_t> cur(adj_ptr.begin(), adj_ptr.end() - 1);
+  // (inc_ptr, inc): the incidence a CSR pattern handle already holds (lists in arrival order)
+  std::vector<int64_t> adj_own;
+  std::unique_ptr<int32_t[]> adj_store;
+  const int64_t *adj_ptr_data = inc_ptr;
+  int32_t *adj_data = inc;
+  if (!inc_ptr) {
+    adj_own.assign(size_t(n_verts) + 1, 0);
+    {
+      std::vector<int64_t> count(size_t(n_verts) + 1, 0);
+      parallel_for(3 * n_elems, [&](int64_t b, int64_t e, int) {
+        for (int64_t k = b; k < e; ++k) __atomic_fetch_add(&count[size_t(conn[k]) + 1], int64_t(1), __ATOMIC_RELAXED);
+      }, 1 << 16);
+      std::partial_sum(count.begin(), count.end(), adj_own.begin());
+    }
+    adj_store.reset(new int32_t[size_t(std::max<int64_t>(3 * n_elems, 1))]);
+    adj_data = adj_store.get();
+    adj_ptr_data = adj_own.data();
+    std::vector<int64_t> cur(adj_own.begin(), adj_own.end() - 1);
     parallel_for(n_elems, [&](int64_t b, int64_t e, int) {
       for (int64_t el = b; el < e; ++el)
         for (int a = 0; a < 3; ++a)
           adj_data[size_t(__atomic_fetch_add(&cur[size_t(conn[3 * el + a])], int64_t(1), __ATOMIC_RELAXED))] = int32_t(el);
     }, 1 << 14);
-    parallel_for(n_verts, [&](int64_t b, int64_t e, int) {
-      for (int64_t v = b; v < e; ++v) std::sort(adj_data + adj_ptr[size_t(v)], adj_data + adj_ptr[size_t(v) + 1]);
-    }, 1 << 14);
   }
+  parallel_for(n_verts, [&](int64_t b, int64_t e, int) {
+    for (int64_t v = b; v < e; ++v) std::sort(adj_data + adj_ptr_data[size_t(v)], adj_data + adj_ptr_data[size_t(v) + 1]);
+  }, 1 << 14);
   lap("vertex -> elements");
   auto reset_plan = [&]() {
     plan.desc.clear();
@@ -762,7 +769,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         }
       }, 64);
       priority_first(specs);
-      const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
+      const int st = emit_plan(conn, adj_ptr_data, adj_data, rowptr, colind, elem_ranges, specs, plan);
       if (st != TFEM_OK) return st;
       if (int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
       if (!chunked) reset_plan();
@@ -819,7 +826,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   }
   lap("greedy tiling along the curve");
   priority_first(specs);
-  const int st = emit_plan(conn, adj_ptr.data(), adj_data, rowptr, colind, elem_ranges, specs, plan);
+  const int st = emit_plan(conn, adj_ptr_data, adj_data, rowptr, colind, elem_ranges, specs, plan);
   lap("emitting tiles");
   return st;
 }
@@ -859,12 +866,12 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
 
 extern "C" {
 
-int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
-                                   const double *coords_host, const int64_t *rowptr_host,
-                                   const int32_t *colind_host, int own_cap, int vert_cap,
-                                   const uint8_t *vertex_priority_host, void **plan_out,
-                                   int64_t *n_priority_tiles) {
-  using namespace tfem;
+namespace tfem {
+namespace {
+int ring_plan_build(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                    const double *coords_host, const int64_t *rowptr_host, const int32_t *colind_host,
+                    int own_cap, int vert_cap, const uint8_t *vertex_priority_host, const int64_t *inc_ptr,
+                    int32_t *inc, void **plan_out, int64_t *n_priority_tiles) {
   if (!plan_out) return fail(TFEM_ERR_INVALID_ARGUMENT, "plan_out is NULL");
   *plan_out = nullptr;
   if (idx_bytes != 4 && idx_bytes != 8)
@@ -882,10 +889,10 @@ int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t
   const bool chunk_mode = !(mode && std::strcmp(mode, "zorder") == 0);
   const int st =
       idx_bytes == 4
-          ? build_rings(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, *plan)
-          : build_rings(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host,
-                        rowptr_host, colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, *plan);
+          ? build_rings(static_cast<const int32_t *>(conn_host), n_elems, n_verts, coords_host, rowptr_host,
+                        colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, inc_ptr, inc, *plan)
+          : build_rings(static_cast<const int64_t *>(conn_host), n_elems, n_verts, coords_host, rowptr_host,
+                        colind_host, own_cap, vert_cap, chunk_mode, vertex_priority_host, inc_ptr, inc, *plan);
   if (st != TFEM_OK) {
     delete plan;
     return st;
@@ -893,6 +900,30 @@ int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t
   *plan_out = plan;
   if (n_priority_tiles) *n_priority_tiles = plan->n_priority;
   return TFEM_OK;
+}
+}  // namespace
+}  // namespace tfem
+
+int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
+                                   const double *coords_host, const int64_t *rowptr_host,
+                                   const int32_t *colind_host, int own_cap, int vert_cap,
+                                   const uint8_t *vertex_priority_host, void **plan_out,
+                                   int64_t *n_priority_tiles) {
+  return tfem::ring_plan_build(conn_host, idx_bytes, n_elems, n_verts, coords_host, rowptr_host, colind_host,
+                               own_cap, vert_cap, vertex_priority_host, nullptr, nullptr, plan_out,
+                               n_priority_tiles);
+}
+
+int tfem_ring_plan_create_from_pattern(void *pattern, const double *coords_host, const int32_t *colind_host,
+                                       int own_cap, int vert_cap, const uint8_t *vertex_priority_host,
+                                       void **plan_out, int64_t *n_priority_tiles) {
+  tfem::PatternView v;
+  if (!tfem::pattern_view(pattern, &v)) return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "pattern is NULL");
+  if (v.n_local != 3)
+    return tfem::fail(TFEM_ERR_INVALID_ARGUMENT, "the ring plan is built from the pattern of a P1 connectivity (3 DoFs per element), got %d", v.n_local);
+  return tfem::ring_plan_build(v.conn, v.idx_bytes, v.n_elems, v.n_dofs, coords_host, v.rowptr, colind_host,
+                               own_cap, vert_cap, vertex_priority_host, v.inc_ptr, v.inc, plan_out,
+                               n_priority_tiles);
 }
 
 int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,

@@ -290,6 +290,34 @@ def test_ring_plan_lists_the_tiles_of_flagged_vertices_first(kind):
         ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=flags[:-1])
 
 
+@pytest.mark.parametrize("kind", ["structured", "delaunay", "delaunay_shuffled"])
+def test_ring_plan_from_the_pattern_handle_is_the_same_plan(kind):
+    """tfem_ring_plan_create_from_pattern (the engine's path: the incidence of the CSR pattern
+    handle is reused) against tfem_ring_plan_create_priority: byte-identical plans."""
+    from pytorch_fem_solver_amd.basis.engine import pattern_host, ring_plan_host
+
+    mesh = _ring_case(kind)
+    nv = mesh["vertices"].shape[0]
+    conn = np.ascontiguousarray(mesh["triangles"].astype(np.int32))
+    rowptr, colind, keeper = pattern_host(conn, nv, keep=True)
+    flags = np.zeros(nv, dtype=bool)
+    flags[::37] = True
+    for priority in (None, flags):
+        alone = ring_plan_host(conn, nv, mesh["vertices"], rowptr, colind, priority=priority)
+        shared = ring_plan_host(conn, nv, mesh["vertices"], rowptr, colind, priority=priority, pattern=keeper)
+        assert np.array_equal(alone["layout"], shared["layout"]) and alone["n_priority"] == shared["n_priority"]
+        assert alone["blob"].tobytes() == shared["blob"].tobytes()
+    keeper.release()
+    assert keeper.handle is None
+    keeper.release()  # idempotent
+    # P2 pattern handles are refused
+    p2 = np.ascontiguousarray(np.tile(np.arange(6, dtype=np.int32), (2, 1)))
+    _, _, k6 = pattern_host(p2, 6, keep=True)
+    with pytest.raises(ValueError):
+        ring_plan_host(conn, nv, mesh["vertices"], rowptr, colind, pattern=k6)
+    k6.release()
+
+
 def test_ring_plan_open_fans_and_isolated_vertices():
     """Two fans meeting in one vertex (a bow tie) chain as two open fans; a vertex without
     elements owns an empty row."""
