@@ -359,8 +359,9 @@ def main():
     elif distributed:
         exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine)
     # interface tiles first: the ring plan lists the tiles that own a shared vertex
-    # first; a step is then two launches -- those tiles, whose rows go to the exchange at once,
-    # and the rest, which runs beside the all-reduce
+    # first; a step is then two launches -- those tiles on the (high-priority) exchange stream,
+    # followed there by pack, all-reduce and unpack of their rows, and the rest on the assembly
+    # stream at the same time
     interface_first = exchange is not None and not args.no_interface_first
     if interface_first:
         engine.set_priority_vertices(exchange.shared_vertices(n_verts))
@@ -372,7 +373,7 @@ def main():
     # the interface all-reduce of step i runs on a side stream and overlaps the assembly
     # launch of step i+1 (steps are independent; every step's exchange completes inside the
     # timed region, which ends with a device-wide synchronise)
-    comm_stream = torch.cuda.Stream(device=device) if distributed else None
+    comm_stream = torch.cuda.Stream(device=device, priority=-1) if distributed else None
 
     # N > 1: the results of step i are still being exchanged while step i+1 assembles, so the
     # steps rotate over three preallocated (vals, f) pairs; before a pair is written again the
@@ -392,8 +393,13 @@ def main():
         slot = counter[0] % depth
         counter[0] += 1
         if interface_first:
-            vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="priority")
-            exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
+            # the exchange stream: interface rows of this pair, then their exchange (ordered behind
+            # the exchange that last used the pair: same stream); the assembly stream: all other rows
+            with torch.cuda.stream(comm_stream):
+                vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="priority")
+                exchange.reduce(vals, f)
+                exchanged[slot] = torch.cuda.Event()
+                exchanged[slot].record(comm_stream)
             engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="rest")
         else:
             vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot])

@@ -1108,6 +1108,21 @@ def test_interface_tiles_first_two_range_launches_equal_one_launch(mesh_kind, lo
     assert torch.equal(out[0], want_v.view(-1))
     if want_f is not None:
         assert same_f(out[1], want_f.view(-1))
+    # bench.py's step: the interface rows and their exchange on a high-priority side stream, the
+    # other rows on the assembly stream at the same time (the launches write disjoint rows)
+    for t in out:
+        t.fill_(float("nan"))
+    torch.cuda.synchronize()
+    fast = torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(fast):
+        one_launch(eng2, out=out, tiles="priority")
+        ex.pack(out[0], out[1] if want_f is not None else None)
+        ex.unpack(out[0], out[1] if want_f is not None else None)
+    one_launch(eng2, out=out, tiles="rest")
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], want_v.view(-1))
+    if want_f is not None:
+        assert same_f(out[1], want_f.view(-1))
     # argument checks of the range entry
     with pytest.raises(ValueError):
         eng2.assemble_system(1.0, 0.5, source=program, tiles="priority")  # needs out=

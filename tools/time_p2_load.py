@@ -1,0 +1,40 @@
+"""P2 load vector at S(707) (BASELINE config 3's mesh): source values from HBM and a source
+program, against the P2 stiffness launch."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import pytorch_fem_solver_amd as tf  # noqa: E402
+from pytorch_fem_solver_amd import meshgen  # noqa: E402
+from pytorch_fem_solver_amd.basis import forms  # noqa: E402
+
+torch.set_default_dtype(torch.float64)
+torch.set_default_device("cuda")
+
+
+def timed(fn, n=100):
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+order = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+basis = tf.Basis(tf.MeshTri(meshgen.unit_square(707, 0.25, 0)), tf.ElementTri(2, order))
+eng = basis._engine
+x, y = forms.SourceExpr(basis, ("x",)), forms.SourceExpr(basis, ("y",))
+program = (x * y + 1.0).program()
+fq = eng.source_values(program)
+print(f"P2, S(707) = {eng.n_elems} elements, {eng.n_dofs} DoFs, order {order} (Q = {eng.n_quad})")
+print(f"K (tfem_p2_assemble_rows)            {timed(lambda: eng.bilinear(1.0, 0.0)):8.1f} us")
+print(f"f from source values (load)          {timed(lambda: eng.load(fq)):8.1f} us")
+print(f"f from a source program              {timed(lambda: eng.load_source(program)):8.1f} us")
+print(f"tfem_source_eval alone               {timed(lambda: eng.source_values(program)):8.1f} us")
