@@ -811,11 +811,17 @@ class AssemblyEngine:
             )
         return v_grad, dx, points, inv
 
-    def bilinear(self, alpha: float, beta: float):
-        """CSR values of alpha*stiffness + beta*mass (fused kernel)."""
+    def bilinear(self, alpha: float, beta: float, out=None):
+        """CSR values of alpha*stiffness + beta*mass (fused kernel).  ``out``: write into this
+        preallocated device buffer of nnz entries (one device copy on the paths whose kernels
+        allocate their own output)."""
+        if out is not None and not self._use_rings():
+            vals = self.bilinear(alpha, beta)
+            self._output(out, vals.numel(), "CSR values").copy_(vals.view(-1))
+            return out
         d = self._inputs()
         if self._use_rings():
-            return self._assemble_rings(alpha, beta)
+            return self._assemble_rings(alpha, beta, out=(out, None))
         if self.tile_plan() is not None:
             return self._assemble_tiles(alpha, beta, want_matrix=True, fq=None)[0]
         csr = self.csr_structure()

@@ -217,7 +217,7 @@ static int launch_rings(const RingLaunch &L) {
                 (long long)t_first, (long long)t_count, (long long)z[0]);
   if (t_count == 0) return TFEM_OK;
   a.n_tiles = int(t_count);
-  a.tile_first = int(t_first);
+  a.off_desc += 80u * unsigned(t_first);  // a tile's index only addresses its descriptor
   a.lds_vert = (int(z[3]) + 1) & ~1;
   // W = sum_q w_q/2 and M_ij = sum_q (w_q/2) l_i l_j, formed in T in quadrature order.  The
   // rules of element_tri.py:77-130 are symmetric, so M has one diagonal and one off-diagonal

@@ -37,8 +37,7 @@ struct RingArgs {
   int xcd_interleave;  // 0: every XCD walks its own contiguous eighth of the tile list
                        // G > 0: the tile list is dealt to the XCDs in blocks of G tiles (one
                        //        front of tiles across the chip)
-  int n_tiles;    // tiles of this launch ...
-  int tile_first; // ... starting at this one of the plan's tile list
+  int n_tiles;    // tiles of this launch (off_desc points at the first one's descriptor)
   int lds_vert;   // vertex slots reserved in LDS
   T stiff_w;      // alpha * sum_q w_q / 2
   T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     const int j = j0 + k * stride;
     const int g = a.xcd_interleave;
     const int t = g ? ((j / g) * 8 + xcd) * g + j % g : xcd * per + j;
-    return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t + a.tile_first : -1);
+    return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
   };
   const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
   const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);

@@ -317,9 +317,14 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
         const int comp = op == TFEM_SRC_PUSH_Y ? 1 : 0;  // wave-uniform
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-          const T v0 = xyc[2 * (codes[e] & 0x3FFu) + comp];
-          const T v1 = xyc[2 * ((codes[e] >> 10) & 0x3FFu) + comp];
-          const T v2 = xyc[2 * ((codes[e] >> 20) & 0x3FFu) + comp];
+          // the LDS addresses are formed here, from the packed ids: formed once in front of the
+          // program loop they cost nine registers the kernel does not have (they went to scratch:
+          // +45 MB of writes per launch at 1e7 elements)
+          unsigned code = codes[e];
+          asm volatile("" : "+v"(code));
+          const T v0 = xyc[2 * (code & 0x3FFu) + comp];
+          const T v1 = xyc[2 * ((code >> 10) & 0x3FFu) + comp];
+          const T v2 = xyc[2 * ((code >> 20) & 0x3FFu) + comp];
 #pragma unroll
           for (int q = 0; q < QL; ++q) s0[e * QL + q] = c * ((lam[0][q] * v0 + lam[1][q] * v1) + lam[2][q] * v2);
         }
