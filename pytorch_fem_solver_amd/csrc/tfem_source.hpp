@@ -41,52 +41,63 @@ int src_depth(const tfem_source_program *in);
 
 #if defined(__HIPCC__)
 
-// sin / cos in fp64 for |x| < 2^30: k = rint(x / pi), r = x - k pi with pi in two doubles (both
-// steps fused multiply-adds: the reduction is exact to ~1e-33 k), the Taylor polynomial of
-// sin to r^21 on [-pi/2, pi/2] (truncation 1.3e-18), sign from the parity of k.  Within
-// 2.3e-16 absolute of the correctly rounded value up to |x| = 1e9 (measured against glibc on
-// 2e7 arguments); 19 instructions against ~60 on the short path of the library function.
+// sin / cos in fp64 for |x| < 1e9: k = rint(x / pi) by adding 1.5 * 2^52 inside one fused
+// multiply-add (the parity of k is then bit 0 of the sum's low word), r = x - k pi with pi in two
+// doubles (both steps fused multiply-adds: the reduction is exact to ~1e-33 k), a degree-17
+// polynomial on [-pi/2, pi/2], sign from the parity of k.  16 instructions per value against
+// ~60 on the short path of the library function; accuracy against correctly rounded values:
+// tests/test_hip_source.py::test_fast_sin_cos_against_correctly_rounded_values.
 // Larger arguments take the library function (wave-uniform branch).
 __device__ __forceinline__ double src_sin_poly(double r) {
+  // r + r^3 P(r^2), P of degree 7: interpolation of (sin r - r) / r^3 at the Chebyshev nodes of
+  // [0, (pi/2)^2] (computed in 60-digit arithmetic, rounded to double): |error| <= 3.6e-17 on
+  // [-pi/2, pi/2] -- two terms fewer than the Taylor polynomial of the same accuracy (r^21)
   const double r2 = r * r;
-  double p = -1.0 / 51090942171709440000.0;
-  p = __builtin_fma(p, r2, 1.0 / 121645100408832000.0);
-  p = __builtin_fma(p, r2, -1.0 / 355687428096000.0);
-  p = __builtin_fma(p, r2, 1.0 / 1307674368000.0);
-  p = __builtin_fma(p, r2, -1.0 / 6227020800.0);
-  p = __builtin_fma(p, r2, 1.0 / 39916800.0);
-  p = __builtin_fma(p, r2, -1.0 / 362880.0);
-  p = __builtin_fma(p, r2, 1.0 / 5040.0);
-  p = __builtin_fma(p, r2, -1.0 / 120.0);
-  p = __builtin_fma(p, r2, 1.0 / 6.0);
-  return __builtin_fma(-(r * r2), p, r);
+  double p = 2.73144475909634011e-15;
+  p = __builtin_fma(p, r2, -7.64397029616579265e-13);
+  p = __builtin_fma(p, r2, 1.60589773124442683e-10);
+  p = __builtin_fma(p, r2, -2.50521076169958777e-08);
+  p = __builtin_fma(p, r2, 2.75573192191632300e-06);
+  p = __builtin_fma(p, r2, -1.98412698412549741e-04);
+  p = __builtin_fma(p, r2, 8.33333333333331587e-03);
+  p = __builtin_fma(p, r2, -1.66666666666666657e-01);
+  return __builtin_fma(r * r2, p, r);
 }
 
 constexpr double kSrcPiHi = 3.141592653589793116e+00, kSrcPiLo = 1.224646799147353207e-16;
 constexpr double kSrcInvPi = 0.318309886183790671537767526745;
 constexpr double kSrcTrigFastMax = 1.0e9;
+constexpr double kSrcRoundMagic = 6755399441055744.0;  // 1.5 * 2^52: x + magic rounds x to an integer
 
-__device__ __forceinline__ double src_flip_sign(double s, int odd) {
+// s with its sign flipped when bit 0 of `parity_word` is set
+__device__ __forceinline__ double src_flip_sign(double s, unsigned parity_word) {
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   u32x2 b = __builtin_bit_cast(u32x2, s);
-  b.y ^= unsigned(odd) << 31;
+  b.y ^= parity_word << 31;
   return __builtin_bit_cast(double, b);
 }
 
+// The low mantissa word of k + magic is k modulo 2^32 (two's complement), |k| < 2^51.
+__device__ __forceinline__ unsigned src_low_word(double kd) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(u32x2, kd).x;
+}
+
 __device__ __forceinline__ double src_sin_fast(double x) {
-  const double k = __builtin_rint(x * kSrcInvPi);
+  const double kd = __builtin_fma(x, kSrcInvPi, kSrcRoundMagic);  // k = rint(x / pi), one rounding
+  const double k = kd - kSrcRoundMagic;
   double r = __builtin_fma(-k, kSrcPiHi, x);
   r = __builtin_fma(-k, kSrcPiLo, r);
-  return src_flip_sign(src_sin_poly(r), int(k) & 1);
+  return src_flip_sign(src_sin_poly(r), src_low_word(kd));
 }
 
 __device__ __forceinline__ double src_cos_fast(double x) {
   // cos x = (-1)^(k+1) sin(x - (k + 1/2) pi), k = rint(x / pi - 1/2)
-  const double k = __builtin_rint(__builtin_fma(x, kSrcInvPi, -0.5));
-  const double kh = k + 0.5;
+  const double kd = __builtin_fma(x, kSrcInvPi, -0.5) + kSrcRoundMagic;
+  const double kh = (kd - kSrcRoundMagic) + 0.5;
   double r = __builtin_fma(-kh, kSrcPiHi, x);
   r = __builtin_fma(-kh, kSrcPiLo, r);
-  return src_flip_sign(src_sin_poly(r), (int(k) & 1) ^ 1);
+  return src_flip_sign(src_sin_poly(r), ~src_low_word(kd));
 }
 
 // A library function applied to every entry with ONE inlined copy of it: the loop is not
@@ -295,6 +306,7 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
 #pragma unroll
   for (int i = 0; i < N; ++i) s0[i] = s1[i] = T(0);
   const int n = prog.n_ops;
+  int depth = 0;  // entries on the stack (wave-uniform)
 #define TFEM_SRC_SET(expr)             \
   _Pragma("unroll") for (int i = 0; i < N; ++i) { \
     const T t = s0[i];                 \
@@ -307,9 +319,14 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
   for (int pc = 0; pc < n; ++pc) {
     const uint32_t op = uint32_t(__builtin_amdgcn_readlane(int(prog.op), pc));
     const T c = src_lane_const<T>(prog, pc);
-    if (op <= TFEM_SRC_PUSH_C) {
+    if (op <= TFEM_SRC_PUSH_C) {  // a push moves the top entry down -- when there is one
+      if (depth > 0) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) s1[i] = s0[i];
+        for (int i = 0; i < N; ++i) s1[i] = s0[i];
+      }
+      ++depth;
+    } else if (op <= TFEM_SRC_DIV_R) {
+      --depth;  // the two-operand operations leave one entry
     }
     switch (op) {
       case TFEM_SRC_PUSH_X:
