@@ -41,6 +41,12 @@ int src_depth(const tfem_source_program *in);
 
 #if defined(__HIPCC__)
 
+template <typename T>
+__device__ __forceinline__ T src_fma(T a, T b, T c) {
+  if constexpr (sizeof(T) == 8) return __builtin_fma(a, b, c);
+  else return __builtin_fmaf(a, b, c);
+}
+
 // sin / cos in fp64 for |x| < 1e9: k = rint(x / pi) by adding 1.5 * 2^52 inside one fused
 // multiply-add (the parity of k is then bit 0 of the sum's low word), r = x - k pi with pi in two
 // doubles (both steps fused multiply-adds: the reduction is exact to ~1e-33 k), a degree-17
@@ -302,9 +308,11 @@ template <typename T, int QL, int NE>
 __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *xyc, const unsigned (&codes)[NE],
                                              const T (&lam)[3][kMaxQuad], T (&out)[NE * QL]) {
   constexpr int N = NE * QL;
+  // no zero fill: a valid program (src_validate) writes an entry before it reads it; the empty
+  // asm gives the registers a defined value without an instruction
   T s0[N], s1[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) s0[i] = s1[i] = T(0);
+  for (int i = 0; i < N; ++i) asm volatile("" : "=v"(s0[i]), "=v"(s1[i]));
   const int n = prog.n_ops;
   int depth = 0;  // entries on the stack (wave-uniform)
 #define TFEM_SRC_SET(expr)             \
@@ -332,19 +340,25 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
       case TFEM_SRC_PUSH_X:
       case TFEM_SRC_PUSH_Y: {
         const int comp = op == TFEM_SRC_PUSH_Y ? 1 : 0;  // wave-uniform
+        // the LDS addresses are formed here, from the packed ids: formed once in front of the
+        // program loop they cost nine registers the kernel does not have (they went to scratch:
+        // +45 MB of writes per launch at 1e7 elements).  All reads are issued before the first use.
+        unsigned code[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-          // the LDS addresses are formed here, from the packed ids: formed once in front of the
-          // program loop they cost nine registers the kernel does not have (they went to scratch:
-          // +45 MB of writes per launch at 1e7 elements)
-          unsigned code = codes[e];
-          asm volatile("" : "+v"(code));
-          const T v0 = xyc[2 * (code & 0x3FFu) + comp];
-          const T v1 = xyc[2 * ((code >> 10) & 0x3FFu) + comp];
-          const T v2 = xyc[2 * ((code >> 20) & 0x3FFu) + comp];
-#pragma unroll
-          for (int q = 0; q < QL; ++q) s0[e * QL + q] = c * ((lam[0][q] * v0 + lam[1][q] * v1) + lam[2][q] * v2);
+          code[e] = codes[e];
+          asm volatile("" : "+v"(code[e]));
         }
+        T vert[NE][3];
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) vert[e][k] = xyc[2 * ((code[e] >> (10 * k)) & 0x3FFu) + comp];
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+          for (int q = 0; q < QL; ++q)  // fused multiply-adds (the file is compiled without contraction)
+            s0[e * QL + q] = c * src_fma<T>(lam[2][q], vert[e][2], src_fma<T>(lam[1][q], vert[e][1], lam[0][q] * vert[e][0]));
         break;
       }
       case TFEM_SRC_PUSH_C: TFEM_SRC_SET(c) break;
