@@ -332,9 +332,9 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
 #pragma unroll
         for (int i = 0; i < N; ++i) s1[i] = s0[i];
       }
-      ++depth;
+      depth = __builtin_amdgcn_readfirstlane(depth + 1);
     } else if (op <= TFEM_SRC_DIV_R) {
-      --depth;  // the two-operand operations leave one entry
+      depth = __builtin_amdgcn_readfirstlane(depth - 1);  // the two-operand operations leave one entry
     }
     switch (op) {
       case TFEM_SRC_PUSH_X:
