@@ -89,8 +89,12 @@ def stiffness_form(basis):  # examples/example_fractures_fem.py:112-116
 
 
 def source_sha():
-    """Digest of the kernel sources: profiles taken from other sources are not quoted."""
+    """Digest of the kernel sources and of the flags they are compiled with: profiles taken from
+    another build are not quoted."""
+    import __graft_entry__ as build
+
     h = hashlib.sha256()
+    h.update(repr((build.HIPCC_FLAGS, sorted(build.PER_FILE_FLAGS.items()))).encode())
     csrc = os.path.join(REPO, "pytorch_fem_solver_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".hip", ".hpp", ".cpp")):

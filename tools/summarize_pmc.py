@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import sys
 from collections import defaultdict
 
 p = argparse.ArgumentParser()
@@ -28,16 +29,11 @@ args = p.parse_args()
 
 
 def source_sha():
-    """bench.source_sha: digest of the kernel sources the profile was taken from."""
-    import hashlib
+    """bench.source_sha: digest of the kernel sources and build flags the profile was taken from."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
 
-    h = hashlib.sha256()
-    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch_fem_solver_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".hpp", ".cpp")):
-            with open(os.path.join(csrc, name), "rb") as fh:
-                h.update(name.encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
+    return bench.source_sha()
 
 
 counters = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
