@@ -1,0 +1,48 @@
+"""BASELINE config 4 on the GPU with more than one rank (-m gpu): N processes of
+tests/dist/check_sharded_assembly.py under torch.distributed.run share the test box's one card and
+exchange over gloo -- shards, ring plans with the interface tiles first, the two-stream step of
+bench.py, pack / all-reduce / unpack -- and every rank compares what it holds with the operator of
+the whole mesh (fp64, 1e-12).  Over RCCL (one rank per GPU) the same script runs with
+--backend nccl; that needs more than one GPU and is the driver's scaling run."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(REPO, "tests", "dist", "check_sharded_assembly.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out_dir, *extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), SCRIPT, "--out-dir", str(out_dir), *extra]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    ranks = []
+    for r in range(world):
+        with open(os.path.join(out_dir, f"rank{r}.json")) as fh:
+            ranks.append(json.load(fh))
+    return ranks
+
+
+@pytest.mark.parametrize("world,layout", [(2, "strips"), (3, "strips"), (2, "partition"), (4, "partition")])
+def test_sharded_assembly_with_interface_tiles_first(world, layout, tmp_path):
+    ranks = _run(world, tmp_path, "--layout", layout)
+    for r in ranks:
+        assert r["err_values"] <= 1e-12 and r["err_vector"] <= 1e-12, r
+        assert 0 < r["priority_tiles"] < r["tiles"], r
+        assert r["interface_entries"] > 0
+    assert len({r["interface_entries"] for r in ranks}) == 1  # one global interface numbering
