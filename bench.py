@@ -391,24 +391,49 @@ def main():
         if exchange is not None and exchanged[counter[0] % depth] is not None:
             torch.cuda.current_stream().wait_event(exchanged[counter[0] % depth])
 
+    # N > 1: every argument of a step's launches is converted once per (vals, f) pair
+    # (engine.prepared_system, exchange.prepared): a step then costs the host four ctypes calls, the
+    # collective and an event -- 47 us against 119 us through the general entry points
+    # (tools/time_step_host_overhead.py), which matters when the per-rank launch is short
+    prepared = []
+    if exchange is not None:
+        for pair in pairs:
+            pack, unpack = exchange.prepared(*pair)
+            if interface_first:
+                prepared.append((engine.prepared_system(1.0, 0.0, pair, source=program, tiles="priority"),
+                                 engine.prepared_system(1.0, 0.0, pair, source=program, tiles="rest"), pack, unpack))
+            else:
+                prepared.append((engine.prepared_system(1.0, 0.0, pair, source=program), None, pack, unpack))
+    events = [torch.cuda.Event() for _ in range(depth)] if exchange is not None else None
+
     def step():
         if exchange is None:
             return engine.assemble_system(1.0, 0.0, source=program)  # one fused launch: K and f
         slot = counter[0] % depth
         counter[0] += 1
+        first, rest, pack, unpack = prepared[slot]
         if interface_first:
             # the exchange stream: interface rows of this pair, then their exchange (ordered behind
             # the exchange that last used the pair: same stream); the assembly stream: all other rows
+            first(comm_stream)
+            pack(comm_stream)
             with torch.cuda.stream(comm_stream):
-                vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="priority")
-                exchange.reduce(vals, f)
-                exchanged[slot] = torch.cuda.Event()
-                exchanged[slot].record(comm_stream)
-            engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot], tiles="rest")
+                dist.all_reduce(exchange.buffer, op=dist.ReduceOp.SUM, group=exchange.group)
+            unpack(comm_stream)
+            events[slot].record(comm_stream)
+            rest()
         else:
-            vals, f = engine.assemble_system(1.0, 0.0, source=program, out=pairs[slot])
-            exchanged[slot] = exchange.reduce_on(comm_stream, vals, f, record=False)
-        return vals, f
+            first()
+            ready = events[slot]
+            ready.record()  # the launch above, on the assembly stream
+            comm_stream.wait_event(ready)
+            pack(comm_stream)
+            with torch.cuda.stream(comm_stream):
+                dist.all_reduce(exchange.buffer, op=dist.ReduceOp.SUM, group=exchange.group)
+            unpack(comm_stream)
+            events[slot].record(comm_stream)
+        exchanged[slot] = events[slot]
+        return pairs[slot]
 
     def barrier():
         if distributed:

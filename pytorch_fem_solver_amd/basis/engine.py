@@ -919,6 +919,45 @@ class AssemblyEngine:
             return fout
         return (vals, fout) if with_load else vals
 
+    def prepared_system(self, alpha, beta, out, fq=None, source=None, tiles=None):
+        """The launch of assemble_system(alpha, beta, fq | source, out=out, tiles=tiles) with every
+        argument converted ONCE: the returned callable only enqueues on the current stream
+        (launch-bound callers: the steps of a sharded run, small meshes).  It holds references to
+        ``out``, ``fq`` and the plan; the source program is copied."""
+        if (fq is None) == (source is None):
+            raise ValueError("prepared_system: source values fq OR a source program")
+        rings = self.ring_plan() if self._use_rings() else None
+        if rings is None or (source is not None and not self._rings_take_source()) or (source is None and not rings["fq_ok"]):
+            raise NotImplementedError("prepared launches need the ring plan of this basis")
+        d = self._inputs()
+        nnz = int(self.csr_structure()[1].shape[0])
+        vals = self._output(out[0], nnz, "CSR values")
+        fout = self._output(out[1], self.n_dofs, "load vector")
+        first, count = self.tile_range(tiles) if tiles is not None else (0, -1)
+        if fq is not None:
+            fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
+        program = None
+        if source is not None:
+            program = _native.SourceProgram()
+            ctypes.memmove(ctypes.byref(program), ctypes.byref(source), ctypes.sizeof(program))
+        fixed = (_native.ptr(d["coords"]), self.real_bytes, self.n_dofs, self.quad_order, float(alpha), float(beta),
+                 _native.ptr(rings["blob"]), c_void_p(rings["layout"].ctypes.data), _native.ptr(vals), nnz,
+                 _native.ptr(fq), ctypes.byref(program) if program is not None else None, self.n_elems,
+                 _native.ptr(fout), int(first), int(count))
+        keep = (d, rings, vals, fout, fq, program)  # what the raw pointers above point into
+        launch_fn, device, check = self.lib.tfem_p1_assemble_rings_range, self.device, _native.check
+        current_stream = torch.cuda.current_stream
+
+        def launch(stream=None):
+            """Enqueue on `stream` (a torch.cuda.Stream; default: the current one)."""
+            handle = (stream if stream is not None else current_stream(device)).cuda_stream
+            status = launch_fn(*fixed, c_void_p(handle))
+            if status:
+                check(status)
+            return keep[2], keep[3]
+
+        return launch
+
     # ------------------------------------------------------------------ source programs
     def supports_source(self):
         """Source programs f(x, y) apply to one 2-D mesh (fracture points are 3-D)."""

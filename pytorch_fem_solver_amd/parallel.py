@@ -117,6 +117,37 @@ class InterfaceExchange:
             args.append(_native.current_stream(buf.device))
             _native.check(getattr(lib, "tfem_interface_" + entry)(*args))
 
+    def prepared(self, vals, f):
+        """(pack, unpack) callables for these device tensors with every argument converted once:
+        each only enqueues its launch on the current stream (the steps of a sharded run are bound
+        by the host otherwise).  The tensors must stay alive and in place."""
+        from . import _native
+
+        buf = self.buffer
+        if not buf.is_cuda:
+            return (lambda stream=None: self.pack(vals, f)), (lambda stream=None: self.unpack(vals, f))
+        lib = _native.load()
+        flat_f = f.view(-1) if f is not None else None
+        ok = lambda t: t is None or (t.is_cuda and t.is_contiguous() and t.dtype == buf.dtype)  # noqa: E731
+        if not (ok(vals) and ok(flat_f)):
+            raise ValueError("interface exchange: vals / f must be contiguous device tensors of the buffer's dtype")
+        head = (_native.ptr(vals), _native.ptr(flat_f), buf.element_size(), _native.ptr(self.k_idx),
+                _native.ptr(self.k_pos), self.k_idx.numel(), _native.ptr(self.f_idx),
+                _native.ptr(self.f_pos), self.f_idx.numel(), _native.ptr(buf))
+        keep = (vals, flat_f)  # noqa: F841  (the pointers above point into them)
+        device, current_stream = buf.device, torch.cuda.current_stream
+        from ctypes import c_void_p
+
+        def run(fn, args):
+            def call(stream=None):
+                handle = (stream if stream is not None else current_stream(device)).cuda_stream
+                status = fn(*args, c_void_p(handle))
+                if status:
+                    _native.check(status)
+            return call
+
+        return run(lib.tfem_interface_pack, head + (buf.numel(),)), run(lib.tfem_interface_unpack, head)
+
     def pack(self, vals=None, f=None):
         """Zero the interface buffer and copy this rank's shared entries into it."""
         buf = self.buffer

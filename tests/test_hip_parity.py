@@ -1132,6 +1132,55 @@ def test_interface_tiles_first_two_range_launches_equal_one_launch(mesh_kind, lo
         eng2._assemble_rings(1.0, 0.5, out=(out[0], None), tiles=(n_all - 1, 2))
 
 
+def test_prepared_launches_enqueue_the_same_work():
+    """engine.prepared_system / InterfaceExchange.prepared (arguments converted once, for the
+    host-bound steps of a sharded run) against the general entry points, on the current stream and
+    on a stream given explicitly."""
+    from pytorch_fem_solver_amd import meshgen, parallel
+    from pytorch_fem_solver_amd.basis import forms
+
+    n = 60
+    mesh_np = meshgen.structured_rectangle(n, n, 0.0, 1.0, 1.0, 2.0, jitter=0.25, seed=0)
+    basis = tf().Basis(tf().MeshTri(triangulation=mesh_np), tf().ElementTri(1, 3))
+    eng = basis._engine
+    ex = parallel.InterfaceExchange.for_strips(mesh_np, 1, 3, eng)
+    eng.set_priority_vertices(ex.shared_vertices(mesh_np["vertices"].shape[0]))
+    program = forms.trace(load, basis, (), {}).coefficient.program()
+    x, y = torch.split(basis.integration_points, 1, dim=-1)
+    fq = rhs(x, y).reshape(-1, eng.n_quad).contiguous()
+    want_v, want_f = eng.assemble_system(1.0, 0.5, source=program)
+    nnz = want_v.numel()
+    side = torch.cuda.Stream()
+    for kw in (dict(source=program), dict(fq=fq)):
+        out = (torch.full((nnz,), float("nan")), torch.full((eng.n_dofs,), float("nan")))
+        whole = eng.prepared_system(1.0, 0.5, out, **kw)
+        got = whole()
+        assert got[0].data_ptr() == out[0].data_ptr() and torch.equal(out[0], want_v.view(-1))
+        assert scaled_error(out[1].cpu(), want_f.view(-1).cpu()) <= 1e-14
+        for t in out:
+            t.fill_(float("nan"))
+        first = eng.prepared_system(1.0, 0.5, out, tiles="priority", **kw)
+        rest = eng.prepared_system(1.0, 0.5, out, tiles="rest", **kw)
+        pack, unpack = ex.prepared(*out)
+        torch.cuda.synchronize()
+        first(side)
+        pack(side)
+        unpack(side)  # one rank: what was packed comes back
+        rest()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want_v.view(-1))
+        assert scaled_error(out[1].cpu(), want_f.view(-1).cpu()) <= 1e-14
+        reference = ex.pack(out[0], out[1]).clone()
+        ex.buffer.zero_()
+        pack()
+        torch.cuda.synchronize()
+        assert torch.equal(ex.buffer, reference)
+    with pytest.raises(ValueError):
+        eng.prepared_system(1.0, 0.5, out)
+    with pytest.raises(ValueError):
+        eng.prepared_system(1.0, 0.5, (out[0][:-1], out[1]), source=program)
+
+
 def test_assembly_launches_can_be_captured_in_a_hip_graph():
     """Launch-bound callers (small meshes, thousands of steps) capture the launch once and
     replay it: the C ABI enqueues on the caller's stream only, so torch.cuda.graph records it.
