@@ -64,6 +64,10 @@ def main():
         chain = ("add", chain, ("c", 1.0 + i))
     chain = forms.compile_program(chain)
     one = forms.compile_program(("c", 1.0))
+    # three values at a time: (x y) ((x + 1) (y + 2)) is evaluated as two products of two operands
+    # each, the second while the first waits on the stack -> the one-element-per-pass interpreter
+    deep = forms.compile_program(("mul", ("mul", ("sin", ("x",)), ("sin", ("y",))),
+                                  ("mul", ("add", ("x",), ("c", 1.0)), ("add", ("y",), ("c", 2.0)))))
     rows = [
         ("K only", lambda: eng.bilinear(1.0, 0.0), algo - 8 * nv),
         ("K + f, fq from memory", lambda: eng.assemble_system(1.0, 0.0, fq), algo),
@@ -71,6 +75,8 @@ def main():
         ("K + f, program x*y+1", lambda: eng.assemble_system(1.0, 0.0, source=poly), algo),
         ("K + f, program constant (1 op)", lambda: eng.assemble_system(1.0, 0.0, source=one), algo),
         ("K + f, program x + 16 constants (17 ops)", lambda: eng.assemble_system(1.0, 0.0, source=chain), algo),
+        ("K + f, program sin x sin y (x+1)(y+2) (stack of 3: one element per pass)",
+         lambda: eng.assemble_system(1.0, 0.0, source=deep), algo),
         ("f only, fq from memory", lambda: eng.load(fq), None),
         ("f only, program sin*sin", lambda: eng.load_source(program), None),
         ("tfem_source_eval sin*sin", lambda: eng.source_values(program), None),
