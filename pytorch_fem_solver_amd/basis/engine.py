@@ -46,7 +46,11 @@ class PatternHandle:
             _native.load().tfem_csr_pattern_destroy(self.handle)
             self.handle = self.conn = None
 
-    __del__ = release
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # interpreter shutdown: the library may be gone already
+            pass
 
 
 def pattern_host(conn_dof, n_dofs, keep=False):
