@@ -46,3 +46,25 @@ def test_sharded_assembly_with_interface_tiles_first(world, layout, tmp_path):
         assert 0 < r["priority_tiles"] < r["tiles"], r
         assert r["interface_entries"] > 0
     assert len({r["interface_entries"] for r in ranks}) == 1  # one global interface numbering
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_runs_with_two_ranks(scaling, tmp_path):
+    """The driver's multi-GPU command line (bench.py under torch.distributed.run), two ranks on the
+    one card over gloo, small mesh: one JSON line from rank 0 with the contract's keys."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "5", "--grid", "256", "--backend", "gloo", "--scaling", scaling]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith('{"metric"')]
+    assert len(lines) == 1, done.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == scaling
+    assert out["value"] > 0 and out["config"]["interface_tiles_first"] is not None
+    n_elems = 2 * 256 * 256
+    assert out["config"]["elements_per_gpu"] == (n_elems if scaling == "weak" else n_elems // 2)
