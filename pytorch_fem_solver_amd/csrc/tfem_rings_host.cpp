@@ -864,8 +864,6 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
 }  // namespace
 }  // namespace tfem
 
-extern "C" {
-
 namespace tfem {
 namespace {
 int ring_plan_build(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
@@ -903,6 +901,9 @@ int ring_plan_build(const void *conn_host, int idx_bytes, int64_t n_elems, int64
 }
 }  // namespace
 }  // namespace tfem
+
+extern "C" {
+
 
 int tfem_ring_plan_create_priority(const void *conn_host, int idx_bytes, int64_t n_elems, int64_t n_verts,
                                    const double *coords_host, const int64_t *rowptr_host,
