@@ -159,6 +159,58 @@ __device__ __forceinline__ void ring_row(const RingArgs<T> &a, const RingRec<SLO
   }
 }
 
+// ring_row for a REGULAR row: six neighbours, six triangles, all of them stored counter-clockwise
+// around the vertex (record: k = 6, flags 1 1 1 1 1 1 0) -- the interior vertices of a structured
+// mesh.  No flag arithmetic, no selection of the closing neighbour; the same operations in the
+// same order as ring_row otherwise (bitwise the same entries).  7-slot records only.
+template <typename T, bool MASS>
+__device__ __forceinline__ void ring_row_regular(const RingArgs<T> &a, const RingRec<7> &rec, uint32_t lv,
+                                                 const T *xy, T (&off)[8], T &diag) {
+  T xv, yv, px, py;
+  lds_xy(xy, lv, xv, yv);
+  lds_xy(xy, rec.id(0), px, py);
+  const T e0x = px - xv, e0y = py - yv;
+  const T q0 = e0x * e0x + e0y * e0y;
+  T ecx = e0x, ecy = e0y, qc = q0;
+  T dsum = T(0), wrapv = T(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) off[i] = T(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    T enx = e0x, eny = e0y, qn = q0;
+    if (i < 5) {
+      lds_xy(xy, rec.id(i + 1), px, py);
+      enx = px - xv;
+      eny = py - yv;
+      qn = enx * enx + eny * eny;
+    }
+    const T p = ecx * enx + ecy * eny;
+    const T cross = ecx * eny - ecy * enx;
+    const T cs = a.stiff_w * fast_rcp<T>(cross);
+    T &behind = i < 5 ? off[i + 1] : wrapv;  // the neighbour behind the triangle (ring_row: off[6] for the last)
+    off[i] = off[i] + cs * (p - qn);
+    behind = behind + cs * (p - qc);
+    if (MASS) {
+      const T m = a.mass_o * cross;
+      off[i] = off[i] + m;
+      behind = behind + m;
+      dsum = dsum + cross;
+    }
+    ecx = enx;
+    ecy = eny;
+    qc = qn;
+  }
+  T sum = off[0];
+#pragma unroll
+  for (int j = 1; j < 6; ++j) sum = sum + off[j];
+  sum = (sum + wrapv) + T(0);  // off[6] = wrapv, off[7] = 0 in ring_row's sum
+  off[0] = off[0] + wrapv;
+  if (MASS)
+    diag = a.mass_d * dsum - (sum - T(2) * a.mass_o * dsum);
+  else
+    diag = -sum;
+}
+
 // Per-wave LDS stage: the wave's CSR entries, compact and in CSR order (row r of the wave
 // starts at the exclusive prefix sum of the row lengths).  Two spare entries behind the
 // 64 * (SLOTS + 1) real ones absorb the slots a row does not have, so staging has no branches.
@@ -737,12 +789,22 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     // ---- B ----
     T off[SLOTS + 1], diag, sdets[SLOTS];
     // wave-uniform: shorter slot loops when no row of this wave needs the long ones
-    constexpr int kBandSlots = (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : SLOTS;
+    // (7-slot records, launches bound by vector issue: the interior vertices of a structured mesh
+    // have six neighbours, the seventh slot of such a wave is empty)
+    constexpr int kBandSlots = (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : (SLOTS == 7 && SRC ? 6 : SLOTS);
     const bool banded = kBandSlots < SLOTS && __builtin_amdgcn_ballot_w64(rec.k() > kBandSlots) == 0;
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
       const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
-      if (banded)
+      bool regular = false;
+      if constexpr (SLOTS == 7 && SRC) {
+        // wave-uniform: every row of the wave (lanes without a row aside) is a regular one
+        const bool mine = ((rec.w[2] >> 10) & 0x3FFFu) == 0x555u && rec.k() == 6;
+        regular = __builtin_amdgcn_ballot_w64(!(mine || my_row >= dc.row1)) == 0;
+      }
+      if (regular) {
+        if constexpr (SLOTS == 7) ring_row_regular<T, MASS>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag);
+      } else if (banded)
         ring_row<T, SLOTS, MASS, FQ, kBandSlots>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);
       else
         ring_row<T, SLOTS, MASS, FQ>(a, rec, lv, xy + cur * 2 * a.lds_vert, off, diag, sdets);

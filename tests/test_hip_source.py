@@ -206,6 +206,33 @@ def test_every_load_path_takes_a_source_program(kernel, name):
             eng.assemble_system(1.0, 0.0, fq=torch.zeros(eng.n_elems, eng.n_quad), source=program)
 
 
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+def test_fused_launch_writes_the_same_matrix_bits_as_the_matrix_only_launch(beta):
+    """The launches with a source program take shortcuts in the row phase (a six-slot loop; a
+    path without flag arithmetic for waves of regular rows: six neighbours, six counter-clockwise
+    triangles).  Same operations in the same order: K must be bit for bit the K of the
+    matrix-only launch -- on a structured mesh (regular interior), on one whose triangles are
+    stored clockwise and on a Delaunay mesh (no regular waves)."""
+    from pytorch_fem_solver_amd import meshgen
+
+    meshes = {
+        "structured": meshgen.unit_square(97, 0.25, 0),
+        "delaunay": meshgen.permute_mesh(meshgen.delaunay_square(9000, 3),
+                                         vertex_order=meshgen.morton_order(meshgen.delaunay_square(9000, 3)["vertices"])),
+    }
+    clockwise = {k: v.copy() for k, v in meshes["structured"].items()}
+    clockwise["triangles"] = np.ascontiguousarray(clockwise["triangles"][:, [0, 2, 1]])
+    meshes["clockwise"] = clockwise
+    for name, mesh_np in meshes.items():
+        basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+        eng = basis._engine
+        _, program = _traced(basis, FIELDS["sin_sin"])
+        assert eng._rings_take_source(), name
+        want = eng.bilinear(1.0, beta)
+        vals, _ = eng.assemble_system(1.0, beta, source=program)
+        assert torch.equal(vals, want), name
+
+
 def test_p2_load_vector_takes_a_source_program():
     d = load_golden("p2_global_n4.npz")
     mesh = tf().MeshTri(triangulation=mesh_from_golden(d))
