@@ -233,6 +233,19 @@ __device__ __forceinline__ int ring_stage(const RingRec<SLOTS> &rec, const T (&o
   return __builtin_amdgcn_readlane(incl, 63);
 }
 
+// ring_stage for a wave of regular rows (ring_row_regular): every row has seven entries, so row r
+// of the wave starts at 7 r -- no scan, no tests (lanes without a row sit behind the last row and
+// write behind `total`, which nothing reads).
+template <typename T>
+__device__ __forceinline__ int ring_stage_regular(const RingRec<7> &rec, const T (&off)[8], T diag, T *stage,
+                                                  int &pre, int n_rows) {
+  pre = 7 * int(threadIdx.x & 63);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) stage[pre + rec.pos(i)] = off[i];
+  stage[pre + rec.dpos()] = diag;
+  return 7 * n_rows;
+}
+
 // The wave's stage -> global memory when the wave's rows form ONE run (a group of rows that is
 // contiguous in the CSR value array): stage index + delta = CSR index for the whole wave.
 // Lane j of step u takes entries 128 u + 2 j and the next one: 16-byte stores, 1 KiB
@@ -793,10 +806,10 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     // have six neighbours, the seventh slot of such a wave is empty)
     constexpr int kBandSlots = (SLOTS > kRingBand && kRingBand > 0) ? kRingBand : (SLOTS == 7 && SRC ? 6 : SLOTS);
     const bool banded = kBandSlots < SLOTS && __builtin_amdgcn_ballot_w64(rec.k() > kBandSlots) == 0;
+    bool regular = false;
     if (!(DBG && (a.flags & 2))) {
       const int my_row = dc.row0 + lane;
       const uint32_t lv = unsigned(my_row < dc.row1 ? my_row : 0);
-      bool regular = false;
       if constexpr (SLOTS == 7 && SRC) {
         // wave-uniform: every row of the wave (lanes without a row aside) is a regular one
         const bool mine = ((rec.w[2] >> 10) & 0x3FFFu) == 0x555u && rec.k() == 6;
@@ -818,9 +831,14 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       t2 = ring_stamp();
     }
     int total = 0, pre = 0;
-    if (KMAT && !(DBG && (a.flags & 8)))
-      total = banded ? ring_stage<T, SLOTS, kBandSlots>(rec, off, diag, my_stage, pre)
-                     : ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+    if (KMAT && !(DBG && (a.flags & 8))) {
+      if (regular) {
+        if constexpr (SLOTS == 7) total = ring_stage_regular<T>(rec, off, diag, my_stage, pre, dc.row1 - dc.row0);
+      } else {
+        total = banded ? ring_stage<T, SLOTS, kBandSlots>(rec, off, diag, my_stage, pre)
+                       : ring_stage<T, SLOTS>(rec, off, diag, my_stage, pre);
+      }
+    }
     T facc = T(0);
     if (SRC) {  // the row's sum is complete: one LDS read
       const int my_row = dc.row0 + lane;
