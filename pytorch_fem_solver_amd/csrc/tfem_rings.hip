@@ -199,6 +199,7 @@ static int launch_rings(const RingLaunch &L) {
     for (int q = 0; q < tables.nq; ++q) {
       a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
       a.lam[i][q] = T(tables.lam[q][i]);
+      a.hw[q] = T(tables.hw[q]);
     }
   if (src) {
     if (z[20] == 0 || z[21] == 0)

@@ -43,6 +43,9 @@ struct RingArgs {
   T mass_d, mass_o;  // beta * sum_q (w_q/2) l_i l_i, beta * sum_q (w_q/2) l_i l_j (i != j)
   T lamw[3][kMaxQuad];  // l_i(q) * w_q / 2 by local vertex i (load vector)
   T lam[3][kMaxQuad];   // l_i(q): the integration points of an element (source programs)
+  T hw[kMaxQuad];       // w_q / 2 (source programs: g_i = sum_q (f_q w_q / 2) l_i(q) needs this and `lam`
+                        // only -- a second table of 3 Q doubles does not fit the scalar registers and
+                        // came back from its spill lanes with two v_readlane per use)
   unsigned off_tverts;  // packed local vertex triples of the tiles' elements (source programs)
   int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
@@ -655,11 +658,14 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
           lds_xy(xyc, (code >> 10) & 0x3FFu, x1, y1);
           lds_xy(xyc, (code >> 20) & 0x3FFu, x2, y2);
           const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+          T fw[QL > 0 ? QL : 1];
+#pragma unroll
+          for (int q = 0; q < QL; ++q) fw[q] = fv[j * (QL > 0 ? QL : 1) + q] * a.hw[q];
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             T g = T(0);
 #pragma unroll
-            for (int q = 0; q < QL; ++q) g = g + fv[j * (QL > 0 ? QL : 1) + q] * a.lamw[i][q];
+            for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
             const unsigned lid = (code >> (10 * i)) & 0x3FFu;
             if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
           }
@@ -694,11 +700,14 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
           // element's three shares go to the accumulators of its vertices (ds_add_f64; the
           // halo vertices' sums are never read)
           const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+          T fw[QL > 0 ? QL : 1];
+#pragma unroll
+          for (int q = 0; q < QL; ++q) fw[q] = fv[q] * a.hw[q];
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             T g = T(0);
 #pragma unroll
-            for (int q = 0; q < QL; ++q) g = g + fv[q] * a.lamw[i][q];
+            for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
             const unsigned lid = (code >> (10 * i)) & 0x3FFu;
             if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
           }
