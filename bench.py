@@ -456,11 +456,16 @@ def main():
         out = step()
     barrier()
 
-    # live launch duration: HIP events on the launch stream around every probe-th step
+    # live launch duration: HIP events on the launch stream around the WHOLE timed region (the
+    # average launch-to-launch time of the K steps: what every other launch of this file is
+    # measured by, event_ms) and around every probe-th step (a single launch between two event
+    # packets reads 2-3 % longer)
     probe = max(1, args.probe_every)
     starts = {i: torch.cuda.Event(enable_timing=True) for i in range(0, args.steps, probe)}
     ends = {i: torch.cuda.Event(enable_timing=True) for i in starts}
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
+    region[0].record()
     for i in range(args.steps):
         claim_pair()
         if i in starts:
@@ -468,13 +473,15 @@ def main():
         out = step()
         if i in ends:
             ends[i].record()
+    region[1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    k_ms = float(np.mean([starts[i].elapsed_time(ends[i]) for i in starts]))
+    k_ms = region[0].elapsed_time(region[1]) / args.steps
+    k_ms_probed = float(np.mean([starts[i].elapsed_time(ends[i]) for i in starts]))
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -553,6 +560,7 @@ def main():
                 "traffic": profile["fused"].get("traffic"),
                 "algorithmic_bytes_per_launch": algo,
                 "kernel_ms": k_ms,
+                "kernel_ms_probed": k_ms_probed,
                 "launch": "fused K + f with the source evaluated in the launch (52 B/element algorithmic, "
                 "SURVEY.md 8(d)); the launch is bound by fp64 vector issue, not by HBM: DESIGN.md section 3",
                 "stiffness_only": {
