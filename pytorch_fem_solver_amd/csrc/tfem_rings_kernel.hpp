@@ -795,7 +795,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       // ---- G ---- source values of tile k (its coordinates are complete).  Before A: the
       // registers of tile k+1's loads are not live while the program runs (3 workgroups per CU)
       compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * kRingBlock);
-      ring_lds_barrier();
+      // (the barrier behind G stands in front of the rows' read of their sums: the next tile's
+      // loads and the rows' own arithmetic need nothing of G)
     }
     // ---- A ----
     if (t_n >= 0) {
@@ -849,7 +850,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       }
     }
     T facc = T(0);
-    if (SRC) {  // the row's sum is complete: one LDS read
+    if (SRC) {  // the row's sum is complete behind the barrier: one LDS read
+      ring_lds_barrier();
       const int my_row = dc.row0 + lane;
       facc = faccbuf[cur * kRingBlock + (my_row < dc.row1 ? my_row : 0)];
     }
