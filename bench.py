@@ -147,41 +147,101 @@ def committed_profile(n, order, kernel):
     return out
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, order):
-    """The C/OpenMP oracle (oracle/assembly_oracle.c: a port of the reference's op sequence,
-    one element per iteration) timed on this host's cores: f(x_q) at the integration points
-    (numpy, as the reference evaluates it with torch on every call), local K + local f +
-    scatter into CSR values / vector -- the same work as one GPU step."""
+    """SURVEY.md 8(d) / BASELINE.md section 4: the reference's own torch op sequence (rows a-1 ...
+    a-9 restated in oracle/torch_restatement.py, pinned to the reference's outputs by
+    tests/test_oracle_golden.py) on this host's cores with torch.set_num_threads(all of them), in
+    three stages -- (1) geometry cache = Basis.__init__, (2) local stage (a(V) * dx).sum(-3) and the
+    local load vector INCLUDING f(x_q) (torch, every call, as the reference evaluates it),
+    (3) global scatter: index_put_(accumulate=True) into the CSR value array through the slot map
+    (the reference's dense target is 2 TB at this size: "not a reference capability") and into the
+    vector.  `value` = elements / (stage 2 + stage 3) = one K + f step on a cached Basis, the work of
+    one GPU step; best of 3 after one warm-up pass.  Second entry: the C/OpenMP port of the same
+    path (oracle/assembly_oracle.c), f(x_q) by torch on all threads as well."""
     import __graft_entry__ as ge
 
     ge.build_oracle()
-    from oracle import assembly_oracle as orc
     from oracle import c_oracle
+    from oracle import torch_restatement as tr
     from pytorch_fem_solver_amd import meshgen
     from pytorch_fem_solver_amd.basis.engine import symbolic_host
 
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     mesh = meshgen.unit_square(n, 0.25, 0)
-    verts, tris = mesh["vertices"], mesh["triangles"]
-    nv = verts.shape[0]
-    _, colind, slots = symbolic_host(tris, nv)  # symbolic phase, not timed (as on the GPU)
-    pts = c_oracle.points(verts, tris, order)   # cached by the reference's Basis, not timed
-    best = float("inf")
+    verts_np, tris_np = mesh["vertices"], mesh["triangles"]
+    nv, n_elems = verts_np.shape[0], tris_np.shape[0]
+    _, colind, slots_np = symbolic_host(tris_np, nv)  # symbolic phase, not timed (as on the GPU)
+    nnz = int(colind.shape[0])
+    verts, tris, slots = torch.from_numpy(verts_np), torch.from_numpy(tris_np), torch.from_numpy(slots_np)
+    stage = {"geometry": [], "local_K": [], "local_f": [], "scatter_K": [], "scatter_f": []}
+    for rep in range(4):
+        t0 = time.perf_counter()
+        geo = tr.geometry_cache(verts, tris, order)
+        t1 = time.perf_counter()
+        k_local = tr.local_bilinear(geo)
+        t2 = time.perf_counter()
+        f_local = tr.local_linear(geo)
+        t3 = time.perf_counter()
+        vals = tr.scatter_bilinear_csr(k_local, slots, nnz)
+        t4 = time.perf_counter()
+        f = tr.scatter_linear(f_local, tris, nv)
+        t5 = time.perf_counter()
+        if rep:  # pass 0 is the warm-up
+            for key, dt in zip(stage, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                stage[key].append(dt)
+        del k_local, f_local, vals, f
+    best = {k: min(v) for k, v in stage.items()}
+    step = best["local_K"] + best["local_f"] + best["scatter_K"] + best["scatter_f"]
+    # the C/OpenMP port: f(x_q) by torch (all threads) on the cached points + one pass per element
+    pts = geo["integration_points"]
+    c_best = float("inf")
     for _ in range(3):
         t0 = time.perf_counter()
-        fq = orc.source_sin_sin(pts)[..., 0]
-        k_local, f_local = c_oracle.p1_local(verts, tris, order, 1.0, 0.0, fq)
-        vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
-        f = c_oracle.scatter_vector(f_local, tris, nv)
-        best = min(best, time.perf_counter() - t0)
-    del vals, f
-    n_elems = tris.shape[0]
+        x, y = torch.split(pts, 1, dim=-1)
+        fq = tr.rhs(x, y).reshape(n_elems, -1).numpy()
+        k_l, f_l = c_oracle.p1_local(verts_np, tris_np, order, 1.0, 0.0, fq)
+        c_oracle.scatter_csr(k_l, slots_np, nnz)
+        c_oracle.scatter_vector(f_l, tris_np, nv)
+        c_best = min(c_best, time.perf_counter() - t0)
     return {
-        "value": n_elems / best / 1e6,
+        "value": n_elems / step / 1e6,
         "unit": "Melements/s",
-        "cores": c_oracle.threads(),
+        "cores": threads,
+        "cpu": cpu_model(),
         "kind": "port",
-        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K+f order {order} incl. f(x_q) (numpy, one "
-        f"thread) + C/OpenMP oracle (oracle/assembly_oracle.c), best of 3",
+        "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K + f order {order}, fp64: the reference's torch op "
+        f"sequence (oracle/torch_restatement.py), torch.set_num_threads({threads}), best of 3 after a warm-up "
+        "pass; value = one K + f step on a cached Basis (local stage incl. f(x_q) + scatter)",
+        "stages_s": {
+            "geometry_cache (Basis.__init__)": best["geometry"],
+            "local_stage ((a(V) * dx).sum(-3): K, and f incl. f(x_q))": best["local_K"] + best["local_f"],
+            "local_K": best["local_K"],
+            "local_f": best["local_f"],
+            "global_scatter (index_put_ into CSR values through the slot map + vector; "
+            "the dense target is not a reference capability at this size)": best["scatter_K"] + best["scatter_f"],
+            "scatter_K": best["scatter_K"],
+            "scatter_f": best["scatter_f"],
+        },
+        "with_geometry_cache": {"value": n_elems / (step + best["geometry"]) / 1e6, "unit": "Melements/s"},
+        "c_port": {
+            "value": n_elems / c_best / 1e6,
+            "unit": "Melements/s",
+            "cores": c_oracle.threads(),
+            "sample": "oracle/assembly_oracle.c (OpenMP, one element per iteration: local K + f, scatter) + "
+            "f(x_q) by torch on the cached points, same mesh, best of 3",
+        },
     }
 
 

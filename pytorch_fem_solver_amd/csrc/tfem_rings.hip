@@ -19,6 +19,9 @@
 // row records 8 B + halo vertex ids ~1 B + coordinates ~9.5 B (halo re-reads included) +
 // values 28.6 B = 47.6 B, against 48 B algorithmic: the 16-byte row records replace the
 // 24 bytes of connectivity the row's triangles take.
+#include <cstdio>
+#include <vector>
+
 #include "tfem_rings_kernel.hpp"
 
 namespace tfem {
@@ -269,9 +272,34 @@ static int launch_rings(const RingLaunch &L) {
   if (L.blocks_per_cu > 0 && L.blocks_per_cu < per_cu) per_cu = L.blocks_per_cu;
   const int blocks = std::min(per * 8, (ring_cu_count() * per_cu / 8) * 8);
   const dim3 grid{unsigned(blocks)}, block{unsigned(kRingBlock)};
+#ifdef TFEM_SRC_TIMING
+  // developer build (tools/ablate_src.py): phase stamps of launch number 300 of a source program
+  static unsigned long long *dev_stamps = nullptr;
+  static int n_launch = 0;
+  const bool stamp_now = src && kmat && ++n_launch == 300;
+  if (stamp_now) {
+    if (!dev_stamps) (void)hipMalloc(&dev_stamps, sizeof(unsigned long long) * 10 * kRingWaves * 8192);
+    a.stamps = dev_stamps;
+  }
+#endif
   void *params[] = {&a};
   hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, L.stream);
   if (e != hipSuccess) return fail(TFEM_ERR_HIP, "ring kernel launch: %s", hipGetErrorString(e));
+#ifdef TFEM_SRC_TIMING
+  if (stamp_now) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(size_t(10) * kRingWaves * size_t(blocks));
+    (void)hipMemcpy(h.data(), dev_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[10] = {0};
+    for (size_t w = 0; w < size_t(kRingWaves) * size_t(blocks); ++w)
+      for (int i = 0; i < 10; ++i) sum[i] += double(h[10 * w + size_t(i)]);
+    const char *names[10] = {"A loads", "B rows", "stage", "vmcnt", "park", "stores", "barrier E", "tiles", "G", "barrier G"};
+    std::fprintf(stderr, "[stamps] %d workgroups, cycles per tile and wave (s_memtime, 100 MHz units x ?):", blocks);
+    for (int i = 0; i < 10; ++i)
+      if (i != 7) std::fprintf(stderr, "  %s %.0f", names[i], sum[i] / sum[7]);
+    std::fprintf(stderr, "  tiles/wave %.1f\n", sum[7] / (double(kRingWaves) * blocks));
+  }
+#endif
   if (kmat && z[23] > 0 && t_first + t_count == z[0]) {  // the rows of the vertices with 8 .. 15 neighbours (with the last tiles)
     const dim3 lgrid{unsigned((16 * z[23] + kRingBlock - 1) / kRingBlock)};  // sixteen lanes per row
     if (mass)

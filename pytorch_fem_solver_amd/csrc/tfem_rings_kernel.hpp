@@ -64,6 +64,12 @@ __device__ __forceinline__ unsigned long long ring_stamp() {
 #ifndef TFEM_RING_BAND
 #define TFEM_RING_BAND 11
 #endif
+// Developer ablation of the source-program launches (tools/ablate_src.py; results are wrong by
+// design): 1 two instead of three elements per lane, 2 no barrier behind phase G, 4 no LDS adds,
+// 8 sin / cos cost nothing (tfem_source.hpp), 16 no phase G at all
+#ifndef TFEM_SRC_ABL
+#define TFEM_SRC_ABL 0
+#endif
 constexpr int kRingBand = TFEM_RING_BAND;  // short slot loop of the 15-slot kernels (0: none)
 
 // Field accessors of a row record (bit layout: tfem_rings_host.cpp).
@@ -642,14 +648,16 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   // the elements' vertices in LDS (element form: no slot codes, nothing per fan slot)
   auto compute_g = [&](const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1], const T *xyc, T *dst) {
     if constexpr (SRC == 2) {
+      if (TFEM_SRC_ABL & 16) return;
       if (wave * 64 >= d.n_elem) return;  // wave-uniform: nothing for this wave in any round
-      unsigned codes[kRingElemPerLane];
+      constexpr int kNE = (TFEM_SRC_ABL & 1) ? 2 : kRingElemPerLane;
+      unsigned codes[kNE];
 #pragma unroll
-      for (int j = 0; j < kRingElemPerLane; ++j) codes[j] = tv[SRC ? j : 0];
-      T fv[kRingElemPerLane * (QL > 0 ? QL : 1)];
-      src_run_wide<T, (QL > 0 ? QL : 1), kRingElemPerLane>(prog, xyc, codes, a.lam, fv);
+      for (int j = 0; j < kNE; ++j) codes[j] = tv[SRC ? j : 0];
+      T fv[kNE * (QL > 0 ? QL : 1)];
+      src_run_wide<T, (QL > 0 ? QL : 1), kNE>(prog, xyc, codes, a.lam, fv);
 #pragma unroll
-      for (int j = 0; j < kRingElemPerLane; ++j) {
+      for (int j = 0; j < kNE; ++j) {
         const int l = tid + j * kRingBlock;
         if (l < d.n_elem) {
           const unsigned code = codes[j];
@@ -667,7 +675,9 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
 #pragma unroll
             for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
             const unsigned lid = (code >> (10 * i)) & 0x3FFu;
-            if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
+            if (TFEM_SRC_ABL & 4) {
+              if (det * g == T(-1.2345e300)) dst[lid] = g;
+            } else if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
           }
         }
       }
@@ -785,29 +795,53 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   gid_halo = gid_halo_ld;
   __syncthreads();
 
+#if defined(TFEM_SRC_STAGGER)
+  if (SRC) {  // developer experiment: workgroups start out of phase
+    const int ph = TFEM_SRC_STAGGER == 1 ? int(blockIdx.x >> 3) & 3 : TFEM_SRC_STAGGER == 2 ? int(blockIdx.x >> 8) & 3
+                                                                                             : int(blockIdx.x >> 5) & 3;
+    for (int i = 0; i < ph * TFEM_SRC_STAGGER_N; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   int cur = 0;
+#ifdef TFEM_SRC_TIMING
+  const bool timing = a.stamps != nullptr;  // developer build: phase stamps of the source-program launch
+#else
   const bool timing = DBG && (a.flags & 256);
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int k = 0;; ++k) {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, tg = 0, tb = 0;
     if (timing) t0 = ring_stamp();
+#ifndef TFEM_SRC_PRIO
+#define TFEM_SRC_PRIO 0
+#endif
+    auto phase_a = [&]() {
+      if (t_n >= 0) {
+        load_tile(dn, gid_own, gid_halo);
+        load_fq(dn, eid);
+        load_tverts(dn, tev_ld);
+        if (t_nn >= 0) {
+          load_ids(dnn, gid_own_ld, gid_halo_ld);
+          load_eids(dnn, eid_ld);
+        }
+      }
+    };
+    if (SRC && (TFEM_SRC_PRIO & 2)) phase_a();
     if (SRC) {
       // ---- G ---- source values of tile k (its coordinates are complete).  Before A: the
       // registers of tile k+1's loads are not live while the program runs (3 workgroups per CU)
+      if (TFEM_SRC_PRIO & 1) __builtin_amdgcn_s_setprio(0);
       compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * kRingBlock);
+      if (TFEM_SRC_PRIO & 1) __builtin_amdgcn_s_setprio(3);
       // (the barrier behind G stands in front of the rows' read of their sums: the next tile's
       // loads and the rows' own arithmetic need nothing of G)
     }
-    // ---- A ----
-    if (t_n >= 0) {
-      load_tile(dn, gid_own, gid_halo);
-      load_fq(dn, eid);
-      load_tverts(dn, tev_ld);
-      if (t_nn >= 0) {
-        load_ids(dnn, gid_own_ld, gid_halo_ld);
-        load_eids(dnn, eid_ld);
-      }
+    if (timing) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tg = ring_stamp();
     }
+    // ---- A ----
+    if (!(SRC && (TFEM_SRC_PRIO & 2))) phase_a();
     if (timing) t1 = ring_stamp();
     // ---- B ----
     T off[SLOTS + 1], diag, sdets[SLOTS];
@@ -850,8 +884,12 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       }
     }
     T facc = T(0);
+    if (timing) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tb = ring_stamp();
+    }
     if (SRC) {  // the row's sum is complete behind the barrier: one LDS read
-      ring_lds_barrier();
+      if (!(TFEM_SRC_ABL & 2)) ring_lds_barrier();
       const int my_row = dc.row0 + lane;
       facc = faccbuf[cur * kRingBlock + (my_row < dc.row1 ? my_row : 0)];
     }
@@ -920,6 +958,10 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     }
     if (timing) {
       t6 = ring_stamp();
+      tsum[8] += tg - t0;  // G
+      tsum[9] += t3 - tb;  // barrier behind G + the read of the row's sum
+      t0 = tg;
+      t3 = tb;  // stage: without that barrier
       tsum[0] += t1 - t0;  // A load issue
       tsum[1] += t2 - t1;  // B rows
       tsum[2] += t3 - t2;  // stage
@@ -955,8 +997,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     cur ^= 1;
   }
   if (timing && a.stamps && lane == 0) {
-    unsigned long long *o = a.stamps + 8 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
-    for (int i = 0; i < 8; ++i) o[i] = tsum[i];
+    unsigned long long *o = a.stamps + 10 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
+    for (int i = 0; i < 10; ++i) o[i] = tsum[i];
   }
 }
 

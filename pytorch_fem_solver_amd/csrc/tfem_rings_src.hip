@@ -10,6 +10,23 @@
 
 namespace tfem {
 
+#ifdef TFEM_SRC_BENCH_ONLY
+// developer build (tools/ablate_src.py): the one instantiation bench.py's step takes
+template <typename T>
+void *pick_ring_src_kernel(int slots, bool mass, bool chunk, int nq, bool kmat, bool wide) {
+  if constexpr (sizeof(T) == 8) {
+    if (slots == 7 && !mass && chunk && nq == 4 && kmat && wide)
+      return reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 4, false, true, 2>);
+    if (slots == 7 && !mass && chunk && nq == 4 && !kmat && wide)
+      return reinterpret_cast<void *>(k_p1_rings<T, 7, false, true, 4, false, false, 2>);
+  }
+  return nullptr;
+}
+template void *pick_ring_src_kernel<double>(int, bool, bool, int, bool, bool);
+template void *pick_ring_src_kernel<float>(int, bool, bool, int, bool, bool);
+}  // namespace tfem
+#else
+
 template <typename T, int SLOTS, bool CHUNK, int SRC>
 static void *pick_src_load_only(int nq) {
   switch (nq) {
@@ -56,3 +73,4 @@ template void *pick_ring_src_kernel<double>(int, bool, bool, int, bool, bool);
 template void *pick_ring_src_kernel<float>(int, bool, bool, int, bool, bool);
 
 }  // namespace tfem
+#endif  // TFEM_SRC_BENCH_ONLY

@@ -387,8 +387,13 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
         }
         break;
       }
+#if defined(TFEM_SRC_ABL) && (TFEM_SRC_ABL & 8)
+      case TFEM_SRC_SIN: TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_COS: TFEM_SRC_SET(c * t) break;
+#else
       case TFEM_SRC_SIN: src_sin<T, N>(s0); TFEM_SRC_SET(c * t) break;
       case TFEM_SRC_COS: src_cos<T, N>(s0); TFEM_SRC_SET(c * t) break;
+#endif
       case TFEM_SRC_EXP:
         if constexpr (sizeof(T) == 8) { TFEM_SRC_WIDE_APPLY(s0, exp) } else { TFEM_SRC_WIDE_APPLY(s0, expf) }
         TFEM_SRC_SET(c * t)

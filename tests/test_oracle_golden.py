@@ -232,3 +232,54 @@ def test_c_oracle_matches_numpy_oracle_and_golden():
         fv = c_oracle.scatter_vector(f, tris, n)
         assert scaled_error(fv.reshape(-1, 1), d[f"out_q{order}_f_load"]) <= TOL
     assert c_oracle.threads() >= 1
+
+
+@pytest.mark.parametrize(
+    "fixture,orders",
+    [
+        ("p1_square_n8.npz", (1, 2, 3, 4)),
+        ("p1_square_n5_clockwise.npz", (3,)),
+        ("p1_delaunay_170.npz", (3,)),
+    ],
+)
+def test_torch_restatement_against_the_reference_outputs(fixture, orders):
+    """oracle/torch_restatement.py (the torch op sequence bench.py's cpu_baseline times, SURVEY.md
+    8(d)) against what the reference itself produced: geometry cache, every form of the fixtures,
+    the dense scatter and the CSR scatter (the non-symmetric form pins the transposed convention)."""
+    import torch
+
+    from oracle import torch_restatement as tr
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        d = load_golden(fixture)
+        verts, tris = torch.from_numpy(d["in_vertices"]), torch.from_numpy(d["in_triangles"])
+        n = verts.shape[0]
+        rowptr, colind, slots = orc.csr_pattern(d["in_triangles"], n)
+        for order in orders:
+            tag = f"out_q{order}_"
+            geo = tr.geometry_cache(verts, tris, order)
+            for key, name in (("v", "v"), ("v_grad", "v_grad"), ("integration_points", "integration_points"),
+                              ("dx", "dx"), ("inv_map_jacobian", "inv_map_jacobian")):
+                assert geo[key].shape == d[tag + name].shape
+                assert scaled_error(geo[key].numpy(), d[tag + name]) <= TOL, key
+            forms = {
+                "K_stiffness": tr.stiffness_integrand,
+                "K_stiffness_mass": tr.stiffness_mass_integrand,
+                "K_convection_x": lambda g: g["v"] @ g["v_grad"][..., [0]].mT,
+            }
+            for name, integrand in forms.items():
+                local = tr.local_bilinear(geo, integrand)
+                dense = tr.scatter_bilinear_dense(local, tris, n)
+                assert scaled_error(dense.numpy(), d[tag + name]) <= TOL, name
+                vals = tr.scatter_bilinear_csr(local, torch.from_numpy(slots), colind.shape[0])
+                assert scaled_error(orc.csr_to_dense(rowptr, colind, vals.numpy(), n), d[tag + name]) <= TOL, name
+            f = tr.scatter_linear(tr.local_linear(geo), tris, n)
+            assert f.shape == d[tag + "f_load"].shape
+            assert scaled_error(f.numpy(), d[tag + "f_load"]) <= TOL
+            x, y = torch.split(geo["integration_points"], 1, dim=-1)
+            fun = tr.functional(geo, lambda g: tr.rhs(x, y) ** 2)
+            assert scaled_error(fun.numpy(), d[tag + "functional_rhs2"]) <= TOL
+    finally:
+        torch.set_default_dtype(prev)
