@@ -53,13 +53,20 @@ def parse():
                    "of stream time per step when recorded around every launch)")
     p.add_argument("--grid", dest="n", type=int, default=2236, help="grid cells per side (N_T = 2 n^2)")
     p.add_argument("--order", type=int, default=3, help="integration order")
-    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                   help="N > 1. strong (default) = BASELINE config 4 as stated: ONE S(2236) mesh cut into N "
+                   "element ranges; weak: one S(2236) strip per rank")
     p.add_argument("--cpu-sample", type=int, default=2236, help="n of the CPU-baseline sample mesh")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel", default="auto", help="auto | rings | tiles | atomic")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    p.add_argument("--no-interface-first", action="store_true",
-                   help="N > 1: one launch per step instead of interface tiles first + the rest")
+    p.add_argument("--interface-first", action="store_true",
+                   help="N > 1: two launches per step, the tiles owning shared rows first (on the exchange "
+                   "stream, in front of their exchange); default: one launch per step, its exchange beside "
+                   "the next step's launch")
+    p.add_argument("--step-mode", choices=("auto", "graph", "eager"), default="auto",
+                   help="N > 1: auto = the steps recorded into HIP graphs over RCCL, eager over gloo")
+    p.add_argument("--graph-steps", type=int, default=6, help="steps per HIP graph (a multiple of 3)")
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the short measurements of the other configurations (P2; Delaunay meshes)")
     p.add_argument("--delaunay-points", type=int, default=1_000_000,
@@ -158,6 +165,26 @@ def cpu_model():
     return "unknown"
 
 
+def host_cpu_share():
+    """Hardware threads this process may actually use: the affinity mask, cut down to the cgroup's
+    CPU quota when there is one (on a shared box the mask shows every core of the host)."""
+    count = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            count = min(count, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                count = min(count, max(1, int(math.ceil(quota / period))))
+        except (OSError, ValueError):
+            pass
+    return count
+
+
 def cpu_baseline(n, order):
     """SURVEY.md 8(d) / BASELINE.md section 4: the reference's own torch op sequence (rows a-1 ...
     a-9 restated in oracle/torch_restatement.py, pinned to the reference's outputs by
@@ -177,8 +204,11 @@ def cpu_baseline(n, order):
     from pytorch_fem_solver_amd import meshgen
     from pytorch_fem_solver_amd.basis.engine import symbolic_host
 
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # every hardware thread this process may use (os.cpu_count() of the host, cut to the container's
+    # CPU quota: 256 threads on a 16-core share ran the same passes 3-4 x slower)
+    threads = host_cpu_share()
     torch.set_num_threads(threads)
+    c_oracle.set_threads(threads)
     mesh = meshgen.unit_square(n, 0.25, 0)
     verts_np, tris_np = mesh["vertices"], mesh["triangles"]
     nv, n_elems = verts_np.shape[0], tris_np.shape[0]
@@ -219,6 +249,7 @@ def cpu_baseline(n, order):
         "value": n_elems / step / 1e6,
         "unit": "Melements/s",
         "cores": threads,
+        "host_cpu_count": os.cpu_count(),
         "cpu": cpu_model(),
         "kind": "port",
         "sample": f"S({n},0.25,0) = {n_elems} elements, P1 K + f order {order}, fp64: the reference's torch op "
@@ -422,80 +453,39 @@ def main():
         del global_mesh
     elif distributed:
         exchange = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, engine)
-    # interface tiles first: the ring plan lists the tiles that own a shared vertex
-    # first; a step is then two launches -- those tiles on the (high-priority) exchange stream,
-    # followed there by pack, all-reduce and unpack of their rows, and the rest on the assembly
-    # stream at the same time
-    interface_first = exchange is not None and not args.no_interface_first
+    # N > 1 (pytorch_fem_solver_amd/parallel.py, ShardedSteps): the launches follow each other on the
+    # assembly stream into three rotating (vals, f) pairs; the exchange of step i -- pack, ONE RCCL
+    # all-reduce of the packed interface entries, unpack -- runs on the exchange stream beside the
+    # launch of step i + 1 (the launch leaves a few CUs free for it); over RCCL the steps are
+    # recorded into HIP graphs (--graph-steps steps each, both streams and the collectives inside),
+    # so a step costs the host a fraction of one graph launch.  --interface-first: the tiles owning
+    # shared rows are launched first, on the exchange stream (two launches per step).
+    interface_first = exchange is not None and args.interface_first
     if interface_first:
         engine.set_priority_vertices(exchange.shared_vertices(n_verts))
+    if distributed:
+        os.environ.setdefault("TFEM_RINGS_RESERVE_CUS", "1")  # one CU per XCD stays free for the exchange
     engine.assemble_system(1.0, 0.0, source=program)  # builds the plans, first launch
     torch.cuda.synchronize()
     setup_ms = (time.perf_counter() - t_mesh) * 1e3  # symbolic phase + plans + device copies
     if interface_first and engine.tile_range("priority")[1] in (0, engine.tile_range("all")[1]):
         interface_first = False  # nothing (or everything) is shared: one launch
-    # the interface all-reduce of step i runs on a side stream and overlaps the assembly
-    # launch of step i+1 (steps are independent; every step's exchange completes inside the
-    # timed region, which ends with a device-wide synchronise)
-    comm_stream = torch.cuda.Stream(device=device, priority=-1) if distributed else None
-
-    # N > 1: the results of step i are still being exchanged while step i+1 assembles, so the
-    # steps rotate over three preallocated (vals, f) pairs; before a pair is written again the
-    # assembly stream waits (on the device, not the host) for the exchange that last used it
-    depth = 3
-    pairs = [(torch.empty(nnz), torch.empty(n_verts)) for _ in range(depth)] if distributed else None
-    exchanged = [None] * depth
-    counter = [0]
-
-    def claim_pair():
-        if exchange is not None and exchanged[counter[0] % depth] is not None:
-            torch.cuda.current_stream().wait_event(exchanged[counter[0] % depth])
-
-    # N > 1: every argument of a step's launches is converted once per (vals, f) pair
-    # (engine.prepared_system, exchange.prepared): a step then costs the host four ctypes calls, the
-    # collective and an event -- 47 us against 119 us through the general entry points
-    # (tools/time_step_host_overhead.py), which matters when the per-rank launch is short
-    prepared = []
+    sharded = None
     if exchange is not None:
-        for pair in pairs:
-            pack, unpack = exchange.prepared(*pair)
-            if interface_first:
-                prepared.append((engine.prepared_system(1.0, 0.0, pair, source=program, tiles="priority"),
-                                 engine.prepared_system(1.0, 0.0, pair, source=program, tiles="rest"), pack, unpack))
-            else:
-                prepared.append((engine.prepared_system(1.0, 0.0, pair, source=program), None, pack, unpack))
-    events = [torch.cuda.Event() for _ in range(depth)] if exchange is not None else None
+        sharded = parallel.ShardedSteps(engine, exchange, 1.0, 0.0, source=program, depth=3,
+                                        interface_first=interface_first)
 
-    def step():
-        if exchange is None:
-            return engine.assemble_system(1.0, 0.0, source=program)  # one fused launch: K and f
-        slot = counter[0] % depth
-        counter[0] += 1
-        first, rest, pack, unpack = prepared[slot]
-        if interface_first:
-            # the exchange stream: interface rows of this pair, then their exchange (ordered behind
-            # the exchange that last used the pair: same stream); the assembly stream: all other rows
-            first(comm_stream)
-            pack(comm_stream)
-            with torch.cuda.stream(comm_stream):
-                dist.all_reduce(exchange.buffer, op=dist.ReduceOp.SUM, group=exchange.group)
-            unpack(comm_stream)
-            events[slot].record(comm_stream)
-            rest()
-        else:
-            first()
-            ready = events[slot]
-            ready.record()  # the launch above, on the assembly stream
-            comm_stream.wait_event(ready)
-            pack(comm_stream)
-            with torch.cuda.stream(comm_stream):
-                dist.all_reduce(exchange.buffer, op=dist.ReduceOp.SUM, group=exchange.group)
-            unpack(comm_stream)
-            events[slot].record(comm_stream)
-        exchanged[slot] = events[slot]
-        return pairs[slot]
+    def run(n):
+        if sharded is not None:
+            return sharded.run(n)
+        out = None
+        for _ in range(n):
+            out = engine.assemble_system(1.0, 0.0, source=program)  # one fused launch: K and f
+        return out
 
     def barrier():
+        if sharded is not None:
+            sharded.sync()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -505,43 +495,55 @@ def main():
     # warm-up steps the caller asked for; reported in config.device_warmup_steps
     # (a fixed count, the same on every rank: the steps of an N > 1 run hold collectives)
     device_warmup_steps = 170
-    for k in range(device_warmup_steps):
-        claim_pair()
-        out = step()
-        if k % 10 == 9:
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        claim_pair()
-        out = step()
+    for k in range(0, device_warmup_steps, 10):
+        run(10)
+        barrier() if sharded is not None else torch.cuda.synchronize()
+    step_mode = "single launch per step"
+    if sharded is not None:
+        want_graph = args.step_mode == "graph" or (args.step_mode == "auto" and args.backend == "nccl")
+        if want_graph and sharded.capture(args.graph_steps):
+            run(2 * args.graph_steps)  # the replays themselves, once, before anything is timed
+            barrier()
+        step_mode = sharded.mode
+    run(args.warmup)
     barrier()
 
     # live launch duration: HIP events on the launch stream around the WHOLE timed region (the
     # average launch-to-launch time of the K steps: what every other launch of this file is
     # measured by, event_ms) and around every probe-th step (a single launch between two event
-    # packets reads 2-3 % longer)
+    # packets reads 2-3 % longer).  N > 1: two streams and a collective per step -- the roofline
+    # figures come from the wall clock of the region instead.
     probe = max(1, args.probe_every)
-    starts = {i: torch.cuda.Event(enable_timing=True) for i in range(0, args.steps, probe)}
+    starts = {i: torch.cuda.Event(enable_timing=True) for i in range(0, args.steps, probe)} if world == 1 else {}
     ends = {i: torch.cuda.Event(enable_timing=True) for i in starts}
     region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
-    region[0].record()
-    for i in range(args.steps):
-        claim_pair()
-        if i in starts:
-            starts[i].record()
-        out = step()
-        if i in ends:
-            ends[i].record()
-    region[1].record()
+    if world == 1:
+        region[0].record()
+        for i in range(args.steps):
+            if i in starts:
+                starts[i].record()
+            out = run(1)
+            if i in ends:
+                ends[i].record()
+        region[1].record()
+        host_s = time.perf_counter() - t0
+    else:
+        out = run(args.steps)
+        host_s = time.perf_counter() - t0  # the host's share: enqueueing (replaying) the steps
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    k_ms = region[0].elapsed_time(region[1]) / args.steps
-    k_ms_probed = float(np.mean([starts[i].elapsed_time(ends[i]) for i in starts]))
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(device)} (cuda:{device.index})")
+    if world == 1:
+        k_ms = region[0].elapsed_time(region[1]) / args.steps
+        k_ms_probed = float(np.mean([starts[i].elapsed_time(ends[i]) for i in starts]))
+    else:
+        k_ms = k_ms_probed = elapsed * 1e3 / args.steps
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -609,6 +611,17 @@ def main():
                 "interface_buffer_bytes": exchange.nbytes if exchange is not None else 0,
                 "interface_tiles_first": (list(engine.tile_range("priority")) + [engine.tile_range("all")[1]]
                                           if interface_first else None),
+                "baseline_config": ("C4: ONE 1e7-element P1 mesh sharded by element range, all-reduce of the shared rows"
+                                    if strong else "C2/C4 kernel on one GPU" if world == 1 else
+                                    "weak-scaling variant of C4 (one 1e7-element strip per GPU)"),
+                "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if distributed else None,
+                "world_size": dist.get_world_size() if distributed else 1,
+                "devices": names if distributed else [f"rank 0: {torch.cuda.get_device_name(device)} (cuda:{device.index})"],
+                "step_mode": step_mode + (f", {sharded.graph_steps} steps per HIP graph" if sharded is not None
+                                          and sharded.mode == "graph" else ""),
+                "graph_capture_error": getattr(sharded, "capture_error", None),
+                "host_us_per_step": host_s * 1e6 / args.steps,
+                "reserved_cus_per_xcd": int(os.environ.get("TFEM_RINGS_RESERVE_CUS", "0")) if distributed else 0,
             },
             "roofline": {
                 "bound": "hbm",
@@ -622,7 +635,9 @@ def main():
                 "kernel_ms": k_ms,
                 "kernel_ms_probed": k_ms_probed,
                 "launch": "fused K + f with the source evaluated in the launch (52 B/element algorithmic, "
-                "SURVEY.md 8(d)); the launch is bound by fp64 vector issue, not by HBM: DESIGN.md section 3",
+                "SURVEY.md 8(d)); the launch is bound by fp64 vector issue, not by HBM: DESIGN.md section 3"
+                + ("" if world == 1 else "; N > 1: kernel_ms = wall clock of the timed region / steps (two streams and a "
+                   "collective per step), achieved = this rank's algorithmic bytes over it"),
                 "stiffness_only": {
                     "kernel_ms": k_only_ms,
                     "cold_ms": float(np.median(cold)),

@@ -300,7 +300,7 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *   create : TFEM_ERR_UNSUPPORTED when the triangles around some vertex do not form
  *            one closed fan or open fans (an edge with three triangles, duplicated or
  *            degenerate elements): use the tile plan for such a mesh.
- *   sizes  : fills layout[24]: [0] n_tiles [1] n_rows [2] n_local_verts
+ *   sizes  : fills layout[32]: [0] n_tiles [1] n_rows [2] n_local_verts
  *            [3] max local verts/tile [4] max owned rows/tile [5] max row length
  *            [6] neighbour slots per row record (7 | 15) [7] dwords per row record (4 | 8)
  *            [8..11] byte offsets of desc, rows, rowstart, vert_gid in the packed plan
@@ -315,6 +315,16 @@ int tfem_p1_assemble_tiles(const void *coords, int real_bytes, int64_t n_verts, 
  *            [21] entries of tile_tverts [22] byte offset and [23] number of the long rows (24-dword
  *            records of the vertices with 8 .. 15 neighbours in a plan with 4-dword records: their
  *            rows are written by a second launch; csrc/tfem_rings_host.cpp)
+ *            [24] byte offset of chain_order (int32 per tile: the order in which the launches that
+ *            evaluate a source program walk the tiles -- along the space-filling curve, the tiles
+ *            owning flagged vertices first) [25] chain length L: a workgroup takes L consecutive
+ *            positions of that order; inside such a block an element in the fans of two
+ *            consecutive tiles is evaluated once, by the earlier one [26] byte offset of hand_in
+ *            (uint16 per owned row, parallel to rowstart: the local id the row's vertex has in the
+ *            PREVIOUS tile of its block, 0xFFFF: none -- the earlier tile sums the shares of all its
+ *            local vertices, the row adds that sum to its own)
+ *            [27] most elements a tile evaluates itself (desc[18] >> 8 of a tile = its count,
+ *            tile_tverts holds exactly those; desc[18] & 0xFF = element-list mode)
  *   pack   : desc int32 (20 per tile: vert_off, n_vert, row_off, first row of wave 0..3 of
  *            the 256-lane workgroup (the first is 0), n_own, vertex id of the first row of
  *            wave 0..3, CSR offset of the first row of wave 0..3, offset into tile_elems,
@@ -327,7 +337,7 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                           int64_t n_verts, const double *coords_host,
                           const int64_t *rowptr_host, const int32_t *colind_host,
                           int own_cap, int vert_cap, void **plan_out);
-int tfem_ring_plan_sizes(const void *plan, int64_t layout[24]);
+int tfem_ring_plan_sizes(const void *plan, int64_t layout[32]);
 int tfem_ring_plan_pack(const void *plan, void *blob_host);
 void tfem_ring_plan_destroy(void *plan);
 int tfem_ring_capacity(int what);

@@ -57,6 +57,16 @@ static int gauss_rule(int order, double nodes[6][2], double w[6]) {
   return nq;
 }
 
+/* n > 0: number of OpenMP threads of the following calls (a container's CPU quota can be far
+ * below the core count omp_get_max_threads() starts from) */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int oracle_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -382,9 +382,7 @@ def csr_pattern(connectivity, n_dofs):
     uniq, inverse = np.unique(key, return_inverse=True)
     urow = uniq // n_dofs
     colind = (uniq % n_dofs).astype(np.int32)
-    rowptr = np.zeros(n_dofs + 1, dtype=np.int64)
-    np.add.at(rowptr, urow + 1, 1)
-    rowptr = np.cumsum(rowptr)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(urow, minlength=n_dofs))]).astype(np.int64)
     n = connectivity.shape[-1]
     return rowptr, colind, inverse.reshape(-1, n, n)
 

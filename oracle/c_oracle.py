@@ -35,6 +35,10 @@ def threads():
     return load().oracle_threads()
 
 
+def set_threads(n):
+    load().oracle_set_threads(int(n))
+
+
 def p1_local(vertices, triangles, order, alpha=1.0, beta=0.0, fq=None, want_k=True):
     """K_local (N_T,3,3) and f_local (N_T,3) (None when fq is None)."""
     lib = load()

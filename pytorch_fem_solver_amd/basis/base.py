@@ -191,6 +191,37 @@ class AbstractBasis(abc.ABC):
                     "detach() the integrand, or differentiate a linear form / functional instead"
                 )
             vals = self._engine.reduce_bilinear(integrand, self._dx)
+        return self._finish_matrix(vals, layout)
+
+    def assemble_system(self, bilinear, linear, *args, layout=None, **kwargs):
+        """``(integrate_bilinear_form(bilinear, ...), integrate_linear_form(linear, ...))`` -- the
+        pair every solve of the reference asks for (examples/example_fractures_fem.py:239-241,
+        tests/test_assembly.py:86-93) -- in ONE launch when both callables are in the fused
+        vocabulary: ``alpha * v_grad @ v_grad.mT + beta * v @ v.mT`` and ``f * v`` with ``f`` an
+        expression of the integration points (evaluated inside the launch) or a tensor of source
+        values.  Anything else: the two calls one after the other, same results."""
+        a_expr = forms.trace(bilinear, self, args, kwargs)
+        l_expr = forms.trace(linear, self, args, kwargs)
+        fused = None
+        if isinstance(a_expr, forms.BilinearExpr) and isinstance(l_expr, forms.LinearExpr) and l_expr.flux is None:
+            coefficient = l_expr.coefficient
+            if isinstance(coefficient, forms.SourceExpr):
+                program = coefficient.program() if self._engine.supports_source() else None
+                if program is not None:
+                    fused = self._engine.assemble_system(a_expr.alpha, a_expr.beta, source=program)
+                else:
+                    coefficient = coefficient.materialize()
+            if fused is None and torch.is_tensor(coefficient) and not coefficient.requires_grad:
+                values = self._source_values(coefficient)
+                if values is not None:
+                    fused = self._engine.assemble_system(a_expr.alpha, a_expr.beta, values)
+        if fused is None:
+            return (self.integrate_bilinear_form(bilinear, *args, layout=layout, **kwargs),
+                    self.integrate_linear_form(linear, *args, **kwargs))
+        vals, f = fused
+        return self._finish_matrix(vals, layout), self._engine._home(f).reshape(-1, 1)
+
+    def _finish_matrix(self, vals, layout):
         matrix = self._engine.wrap_csr(vals)
         n = matrix.shape[0]
         if layout is None:

@@ -208,7 +208,7 @@ def ring_plan_host(conn, n_verts, coords, rowptr, colind, own_cap=None, vert_cap
             )
         )
     try:
-        layout = np.zeros(24, dtype=np.int64)
+        layout = np.zeros(32, dtype=np.int64)
         _native.check(lib.tfem_ring_plan_sizes(handle, c_void_p(layout.ctypes.data)))
         blob = np.empty(int(layout[12]), dtype=np.uint8)  # pack writes every byte
         _native.check(lib.tfem_ring_plan_pack(handle, c_void_p(blob.ctypes.data)))
@@ -242,6 +242,12 @@ def unpack_ring_plan(blob, layout):
         "tile_tverts": np.frombuffer(blob, dtype=np.uint32, count=z[21], offset=z[20]),
         "long_rows": np.frombuffer(blob, dtype=np.uint32, count=24 * z[23], offset=z[22]),
         "elems_staged": bool(z[18]),
+        # source-program launches: walk order of the tiles, positions per workgroup block, and per
+        # owned row the local id its vertex has in the previous tile of its block (0xFFFF: none)
+        "chain_order": np.frombuffer(blob, dtype=np.int32, count=z[0], offset=z[24]),
+        "chain_len": z[25],
+        "hand_in": np.frombuffer(blob, dtype=np.uint16, count=z[1], offset=z[26]),
+        "max_n_tv": z[27],
     }
 
 
@@ -629,6 +635,10 @@ class AssemblyEngine:
         if rings is None:
             raise NotImplementedError("tile ranges need the ring plan")
         n, p = rings["n_tiles"], rings["n_priority"]
+        if which != "all" and int(rings["layout"][23]) > 0:
+            # the rows of vertices with 8 .. 15 neighbours (TFEM_RING_LONG=1 plans) are written by a
+            # launch of their own over ALL of them: a part of the tiles would leave some unwritten
+            raise NotImplementedError("tile ranges are not available for a ring plan with long rows")
         try:
             return {"priority": (0, p), "rest": (p, n - p), "all": (0, n)}[which]
         except KeyError:

@@ -20,6 +20,7 @@
 // values 28.6 B = 47.6 B, against 48 B algorithmic: the 16-byte row records replace the
 // 24 bytes of connectivity the row's triangles take.
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "tfem_rings_kernel.hpp"
@@ -195,9 +196,12 @@ static int launch_rings(const RingLaunch &L) {
   if (load && !src && z[23] > 0)
     return fail(TFEM_ERR_UNSUPPORTED, "a ring plan with long rows takes the load vector of a source program, "
                 "not of pre-evaluated source values");
-  if (load && (z[18] == 0 || z[17] > kRingElemPerLane * kRingBlock))
+  if (load && !src && (z[18] == 0 || z[17] > kRingElemPerLane * kRingBlock))
     return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan has %lld elements: the fused load "
                 "vector stages at most %d", (long long)z[17], kRingElemPerLane * kRingBlock);
+  if (src && z[27] > kRingElemPerLane * kRingBlock)
+    return fail(TFEM_ERR_UNSUPPORTED, "a tile of the ring plan evaluates %lld elements: the launch "
+                "takes at most %d", (long long)z[27], kRingElemPerLane * kRingBlock);
   for (int i = 0; i < 3; ++i)
     for (int q = 0; q < tables.nq; ++q) {
       a.lamw[i][q] = T(tables.lam[q][i]) * T(tables.hw[q]);
@@ -208,6 +212,11 @@ static int launch_rings(const RingLaunch &L) {
     if (z[20] == 0 || z[21] == 0)
       return fail(TFEM_ERR_UNSUPPORTED, "the ring plan carries no element vertex table (source programs)");
     a.off_tverts = unsigned(z[20]);
+    a.off_chain = unsigned(z[24]);
+    a.off_hin = unsigned(z[26]);
+    a.chain_len = int(z[25]);
+    if (a.chain_len < 1 || z[24] == 0 || z[26] == 0)
+      return fail(TFEM_ERR_INVALID_ARGUMENT, "the ring plan carries no chain order (layout of an older build?)");
     const int st = src_convert<T>(L.source, &a.src);
     if (st != TFEM_OK) return st;
   }
@@ -219,9 +228,18 @@ static int launch_rings(const RingLaunch &L) {
   if (t_first < 0 || t_count < 0 || t_first + t_count > z[0])
     return fail(TFEM_ERR_INVALID_ARGUMENT, "tile range [%lld, +%lld) outside the plan's %lld tiles",
                 (long long)t_first, (long long)t_count, (long long)z[0]);
+  if (kmat && z[23] > 0 && (t_first != 0 || t_count != z[0]))
+    return fail(TFEM_ERR_UNSUPPORTED, "a ring plan with long rows is launched over all of its tiles: the rows of "
+                "the vertices with 8 .. 15 neighbours are written by one launch over all of them");
   if (t_count == 0) return TFEM_OK;
   a.n_tiles = int(t_count);
-  a.off_desc += 80u * unsigned(t_first);  // a tile's index only addresses its descriptor
+  // a tile's index only addresses its descriptor; the launches of a source program walk positions
+  // [t_first, t_first + t_count) of the chain order instead (the same tiles for the ranges the
+  // plan knows: the tiles owning flagged vertices come first in both orders)
+  if (src)
+    a.u_first = int(t_first);
+  else
+    a.off_desc += 80u * unsigned(t_first);
   a.lds_vert = (int(z[3]) + 1) & ~1;
   // W = sum_q w_q/2 and M_ij = sum_q (w_q/2) l_i l_j, formed in T in quadrature order.  The
   // rules of element_tri.py:77-130 are symmetric, so M has one diagonal and one off-diagonal
@@ -240,7 +258,8 @@ static int launch_rings(const RingLaunch &L) {
   a.lds_elem = load ? int(z[17]) : 0;
   const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) +
                      (kmat ? size_t(kRingWaves) * size_t(64 * (slots + 1) + 2) * sizeof(T) : 0) +
-                     (src ? size_t(2 * kRingBlock) * sizeof(T) : load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
+                     (src ? size_t(3 * (a.lds_vert + 2)) * sizeof(T)  // three buffers of sums per local vertex
+                          : load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
   a.stamps = L.stamps;
@@ -259,18 +278,41 @@ static int launch_rings(const RingLaunch &L) {
                        : reinterpret_cast<void *>(k_p1_rings<T, 7, false, false, 0, true>);
     }
   }
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  // resident workgroups: what LDS and registers allow per CU, on every CU.  The answer (and the
+  // one-off attribute for more than 64 KB of LDS) is kept per (kernel, LDS size): the launch path
+  // of a prepared step does no runtime query
+  struct Occupancy { void *kernel; size_t lds; int per_cu; };
+  static Occupancy occ_cache[16];
+  static int occ_used = 0;
+  static std::mutex occ_mutex;
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> guard(occ_mutex);
+    for (int i = 0; i < occ_used; ++i)
+      if (occ_cache[i].kernel == kernel && occ_cache[i].lds == lds) per_cu = occ_cache[i].per_cu;
+    if (per_cu == 0) {
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      }
+      hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRingBlock, lds);
+      if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+      if (occ_used < 16) occ_cache[occ_used++] = {kernel, lds, per_cu};
+    }
   }
   const int deal = a.xcd_interleave > 0 ? a.xcd_interleave : 1;
-  const int per = int((t_count + 8 * deal - 1) / (8 * deal)) * deal;
-  // resident workgroups: what LDS and registers allow per CU, on every CU
-  int per_cu = 0;
-  hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kRingBlock, lds);
-  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  int per = int((t_count + 8 * deal - 1) / (8 * deal)) * deal;
+  if (src) {  // blocks of the chain order, dealt to the XCDs round-robin: workgroups per XCD that get one
+    const int64_t first_block = t_first / a.chain_len, last_block = (t_first + t_count - 1) / a.chain_len;
+    per = int((last_block - first_block + 1 + 7) / 8);
+  }
   if (L.blocks_per_cu > 0 && L.blocks_per_cu < per_cu) per_cu = L.blocks_per_cu;
-  const int blocks = std::min(per * 8, (ring_cu_count() * per_cu / 8) * 8);
+  // TFEM_RINGS_RESERVE_CUS: CUs per XCD this launch leaves free (a sharded step: the kernels of
+  // the interface exchange of the previous step -- pack, RCCL's all-reduce, unpack -- find room
+  // beside the persistent workgroups of this one)
+  int cus = ring_cu_count();
+  if (const char *v = std::getenv("TFEM_RINGS_RESERVE_CUS")) cus = std::max(8, cus - 8 * std::max(0, std::atoi(v)));
+  const int blocks = std::min(per * 8, (cus * per_cu / 8) * 8);
   const dim3 grid{unsigned(blocks)}, block{unsigned(kRingBlock)};
 #ifdef TFEM_SRC_TIMING
   // developer build (tools/ablate_src.py): phase stamps of launch number 300 of a source program
@@ -300,7 +342,7 @@ static int launch_rings(const RingLaunch &L) {
     std::fprintf(stderr, "  tiles/wave %.1f\n", sum[7] / (double(kRingWaves) * blocks));
   }
 #endif
-  if (kmat && z[23] > 0 && t_first + t_count == z[0]) {  // the rows of the vertices with 8 .. 15 neighbours (with the last tiles)
+  if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours
     const dim3 lgrid{unsigned((16 * z[23] + kRingBlock - 1) / kRingBlock)};  // sixteen lanes per row
     if (mass)
       hipLaunchKernelGGL((k_p1_long_rows<T, true>), lgrid, block, 0, L.stream, a.coords, a.plan, unsigned(z[22]),

@@ -48,7 +48,7 @@
 namespace tfem {
 
 constexpr int kRingDescStride = 20;
-constexpr int kRingLayoutLen = 24;
+constexpr int kRingLayoutLen = 32;
 constexpr int kRingElemCap = 768;  // elements staged per tile: three per lane of the kernel
 constexpr int kRingElemRuns = 8;   // runs of consecutive element ids a tile may store instead of its list
 constexpr int kRingHaloCapHost = 256;  // halo vertices per tile: one per lane of the kernel
@@ -82,6 +82,18 @@ struct RingPlan {
   bool chunked = false;           // every wave's 64 rows are 64 consecutive vertices
   bool long_mode = false;         // 4-dword records + long rows instead of 8-dword records
   int64_t n_priority = 0;         // leading tiles that own a flagged vertex (tfem_ring_plan_create_priority)
+  // Source-program launches (element form of the load vector) walk the tiles in CHAIN ORDER: the
+  // tiles along the space-filling curve (spatial neighbours one after the other; the tiles owning
+  // flagged vertices first), cut into blocks of `chain_len` positions that one workgroup takes in
+  // a row.  Inside a block an element shared by consecutive tiles is evaluated ONCE, by the earlier
+  // tile, which sums the shares of ALL its local vertices; a row of the later tile adds what the
+  // earlier tile summed for its vertex (`hand_in`: per owned row the local id its vertex has in the
+  // previous tile of the block, 0xFFFF: none) to its own sum; tile_tverts lists per tile only the
+  // elements the tile evaluates itself.
+  std::vector<int32_t> chain_order;  // position in the chain order -> tile
+  std::vector<uint16_t> hand_in;     // parallel to rowstart
+  int32_t chain_len = 1;
+  int32_t max_n_tv = 0;              // most elements a tile evaluates itself
 };
 
 namespace {
@@ -246,6 +258,7 @@ struct TileMap {
 struct TileSpec {
   std::vector<int32_t> owned;
   int32_t wave_start[5] = {0, 0, 0, 0, 0};
+  int32_t curve_rank = 0;  // position of the tile along the space-filling curve
 };
 
 // What the tiles of one thread add to the plan arrays (a thread takes a contiguous range of
@@ -552,6 +565,96 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
   return TFEM_OK;
 }
 
+// Blocks of the chain order one workgroup takes in a row.  Measured at S(2236) = 20,147 tiles on
+// 1024 resident workgroups (profiles/r03_chain_sweep.log): the fused K + f launch of sin * sin takes
+// 190 us with blocks of 1, 184 with 4, 172 with 8 and 16 (the doubly evaluated elements drop from
+// 27 % to 9 / 6 / 5 %), 239 with 32 (too few blocks per workgroup).  Blocks of up to 8, as long as
+// every workgroup still gets two of them.
+int pick_chain_len(int64_t n_tiles) {
+  if (const char *v = std::getenv("TFEM_RING_CHAIN")) return std::max(1, std::min(std::atoi(v), 64));
+  int64_t wgs = 1024;  // resident workgroups of the launch: 4 per CU of an MI355X
+  if (const char *v = std::getenv("TFEM_RING_WGS")) wgs = std::max(1, std::atoi(v));
+  return int(std::max<int64_t>(1, std::min<int64_t>(8, n_tiles / (2 * wgs))));
+}
+
+// Chain order, per-tile tables of the elements a tile evaluates itself, carry maps (RingPlan).
+// Works on the assembled plan: a tile's full element list (tile_elems / its runs) and vertex table
+// (tile_tverts, same order) are filtered, vert_gid tells which halo vertices the next tile owns.
+void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
+  const int64_t n_tiles = plan.n_tiles;
+  plan.chain_order.resize(size_t(n_tiles));
+  std::iota(plan.chain_order.begin(), plan.chain_order.end(), 0);
+  auto by_curve = [&](int32_t x, int32_t y) { return specs[size_t(x)].curve_rank < specs[size_t(y)].curve_rank; };
+  std::sort(plan.chain_order.begin(), plan.chain_order.begin() + plan.n_priority, by_curve);
+  std::sort(plan.chain_order.begin() + plan.n_priority, plan.chain_order.end(), by_curve);
+  const int len = pick_chain_len(n_tiles);
+  plan.chain_len = len;
+  plan.hand_in.assign(plan.rowstart.size(), uint16_t(0xFFFF));
+  const int64_t n_blocks = (n_tiles + len - 1) / len;
+  std::vector<std::vector<uint32_t>> kept(static_cast<size_t>(n_tiles));
+  int32_t *desc = plan.desc.data();
+  auto elem_id = [&](const int32_t *d, int32_t j) {  // j-th element of the tile's ascending list
+    const int32_t *te = plan.tile_elems.data() + d[16];
+    if (!d[18]) return te[j];
+    int32_t id = te[0] + j;
+    for (int r = 1; r < kRingElemRuns; ++r)
+      if (j >= te[kRingElemRuns + r - 1]) id = te[r] + (j - te[kRingElemRuns + r - 1]);
+    return id;
+  };
+  parallel_for(n_blocks, [&](int64_t b0, int64_t b1, int) {
+    TileMap prev(16384), cur(16384), prev_local(2048);
+    for (int64_t b = b0; b < b1; ++b) {
+      bool have_prev = false;
+      for (int64_t u = b * len; u < std::min<int64_t>((b + 1) * len, n_tiles); ++u) {
+        // positions n_priority - 1 and n_priority belong to different launches: no hand-over
+        if (u == plan.n_priority) have_prev = false;
+        const int32_t t = plan.chain_order[size_t(u)];
+        const int32_t *d = desc + size_t(t) * kRingDescStride;
+        const int32_t n_elem = d[17];
+        const uint32_t *codes = plan.tile_tverts.data() + d[19];
+        std::vector<uint32_t> &mine = kept[size_t(t)];
+        mine.reserve(size_t(n_elem));
+        cur.clear();
+        for (int32_t j = 0; j < n_elem; ++j) {
+          const int32_t e = elem_id(d, j);
+          if (have_prev && prev.has(e)) continue;  // the tile before evaluates it and hands the shares over
+          cur.put(e, 0);
+          mine.push_back(codes[j]);
+        }
+        if (have_prev) {  // where the tile before summed the shares of this tile's vertices
+          const int32_t *dp = desc + size_t(plan.chain_order[size_t(u) - 1]) * kRingDescStride;
+          prev_local.clear();
+          for (int32_t l = dp[7]; l < dp[1]; ++l) prev_local.put(plan.vert_gid[size_t(dp[0]) + size_t(l)], l);
+          for (int32_t r = 0; r < d[7]; ++r) {
+            const int32_t g = plan.vert_gid[size_t(d[0]) + size_t(r)];
+            if (prev_local.has(g)) plan.hand_in[size_t(d[2]) + size_t(r)] = uint16_t(prev_local.get(g));
+          }
+        }
+        const bool has_next = u + 1 < std::min<int64_t>((b + 1) * len, n_tiles) && u + 1 != plan.n_priority;
+        std::swap(prev, cur);
+        have_prev = has_next;
+      }
+    }
+  }, 16);
+  // the tables, in tile order
+  int64_t total = 0;
+  plan.max_n_tv = 0;
+  for (int64_t t = 0; t < n_tiles; ++t) {
+    int32_t *d = desc + size_t(t) * kRingDescStride;
+    const int32_t n_tv = int32_t(kept[size_t(t)].size());
+    d[18] = (d[18] & 0xFF) | (n_tv << 8);
+    d[19] = int32_t(total);
+    total += n_tv;
+    plan.max_n_tv = std::max(plan.max_n_tv, n_tv);
+  }
+  std::vector<uint32_t> tv(static_cast<size_t>(total));
+  parallel_for(n_tiles, [&](int64_t b, int64_t e, int) {
+    for (int64_t t = b; t < e; ++t)
+      std::copy(kept[size_t(t)].begin(), kept[size_t(t)].end(), tv.begin() + desc[size_t(t) * kRingDescStride + 19]);
+  }, 256);
+  plan.tile_tverts.swap(tv);
+}
+
 template <typename I>
 int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *coords,
                 const int64_t *rowptr, const int32_t *colind, int own_cap, int vert_cap,
@@ -648,6 +751,10 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.elems_staged = true;
     plan.max_n_vert = plan.max_n_own = plan.max_n_halo = 0;
     plan.n_tiles = 0;
+    plan.chain_order.clear();
+    plan.hand_in.clear();
+    plan.chain_len = 1;
+    plan.max_n_tv = 0;
   };
   std::vector<int32_t> vert_stamp(size_t(n_verts), -1);
   std::vector<TileSpec> specs;
@@ -664,6 +771,9 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     // (the end of a grid line): more than 32 mean vertex spacings to the next vertex
     const double spacing = std::sqrt(std::max((hi[0] - lo[0]) * (hi[1] - lo[1]), 1e-300) / double(n_verts));
     const double jump2 = 32.0 * 32.0 * spacing * spacing;
+    // TFEM_RING_CHUNK (developer switch): widest chunk, <= 64 rows of a wave
+    int chunk_width = 64;
+    if (const char *v = std::getenv("TFEM_RING_CHUNK")) chunk_width = std::max(8, std::min(std::atoi(v), 64));
     std::vector<int32_t> chunk_first;  // first vertex of every chunk, + n_verts as sentinel
     for (int64_t seg0 = 0; seg0 < n_verts;) {
       int64_t seg1 = seg0 + 1;  // [seg0, seg1): a piece of the numbering without a jump
@@ -672,8 +782,8 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         const double dy = coords[2 * seg1 + 1] - coords[2 * seg1 - 1];
         if (dx * dx + dy * dy > jump2) break;
       }
-      // ceil(length / 64) chunks of equal size (+-1): every wave equally loaded
-      const int64_t len = seg1 - seg0, parts = (len + 63) / 64;
+      // ceil(length / width) chunks of equal size (+-1): every wave equally loaded
+      const int64_t len = seg1 - seg0, parts = (len + chunk_width - 1) / chunk_width;
       for (int64_t c = 0; c < parts; ++c) chunk_first.push_back(int32_t(seg0 + c * len / parts));
       seg0 = seg1;
     }
@@ -703,7 +813,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     // tiles the resident workgroups work on at the same time cover long contiguous ranges of
     // the coordinate, source-value and CSR value arrays (TFEM_RING_ORDER=curve keeps curve order)
     std::vector<int32_t> tile_chunks, chunk_fresh;
-    std::vector<std::vector<int32_t>> groups;
+    std::vector<std::vector<int32_t>> groups;  // last entry of every group: its rank along the curve
     int64_t ccursor = 0;
     int32_t probe = -2;  // stamp values of pass 1: negative, distinct from every tile id
     int64_t probe_local = 0, probe_rows = 0;
@@ -742,6 +852,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       }
       if (!chunked) break;
       std::sort(tile_chunks.begin(), tile_chunks.end());
+      tile_chunks.push_back(int32_t(groups.size()));
       groups.push_back(tile_chunks);
       probe_local += n_local;
       probe_rows += n_owned_rows;
@@ -760,9 +871,10 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
         for (int64_t t = b; t < e; ++t) {
           const std::vector<int32_t> &g = groups[size_t(t)];
           TileSpec &spec = specs[size_t(t)];
+          spec.curve_rank = g.back();
           for (int w = 0; w < 5; ++w) {
             spec.wave_start[w] = int32_t(spec.owned.size());  // one chunk per wave
-            if (w < int(g.size()))
+            if (w + 1 < int(g.size()))
               for (int32_t v = chunk_first[size_t(g[size_t(w)])]; v < chunk_first[size_t(g[size_t(w)]) + 1]; ++v)
                 spec.owned.push_back(v);
           }
@@ -773,8 +885,10 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
       if (st != TFEM_OK) return st;
       if (int64_t(plan.vert_gid.size()) > 2 * n_verts) chunked = false;
       if (!chunked) reset_plan();
+      lap("emitting tiles");
+      if (chunked) chain_pass(specs, plan);
+      lap("chain order, element tables");
     }
-    lap("emitting tiles");
   }
   plan.chunked = chunked;
   if (chunked) return TFEM_OK;
@@ -821,6 +935,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     // owned rows ascending (contiguous output runs), 64 per wave
     std::sort(spec.owned.begin(), spec.owned.end());
     for (int w = 0; w < 5; ++w) spec.wave_start[w] = std::min<int32_t>(64 * w, int32_t(spec.owned.size()));
+    spec.curve_rank = tile;
     specs.push_back(std::move(spec));
     ++tile;
   }
@@ -828,6 +943,8 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
   priority_first(specs);
   const int st = emit_plan(conn, adj_ptr_data, adj_data, rowptr, colind, elem_ranges, specs, plan);
   lap("emitting tiles");
+  if (st == TFEM_OK) chain_pass(specs, plan);
+  lap("chain order, element tables");
   return st;
 }
 
@@ -841,13 +958,14 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[8] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
-                            int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
-                            int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4,
-                            int64_t(p.tile_tverts.size()) * 4, int64_t(p.long_rows.size()) * 4};
-  const int slot_of[8] = {8, 9, 10, 11, 15, 16, 20, 22};
+  const int64_t bytes[10] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+                             int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
+                             int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4,
+                             int64_t(p.tile_tverts.size()) * 4, int64_t(p.long_rows.size()) * 4,
+                             int64_t(p.chain_order.size()) * 4, int64_t(p.hand_in.size()) * 2};
+  const int slot_of[10] = {8, 9, 10, 11, 15, 16, 20, 22, 24, 26};
   int64_t off = 0;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 10; ++i) {
     layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
@@ -859,6 +977,8 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[23] = int64_t(p.long_rows.size() / 24);
   layout[13] = p.chunked ? 1 : 0;
   layout[14] = p.max_n_halo;
+  layout[25] = p.chain_len;
+  layout[27] = p.max_n_tv;
 }
 
 }  // namespace
@@ -934,7 +1054,7 @@ int tfem_ring_plan_create(const void *conn_host, int idx_bytes, int64_t n_elems,
                                         colind_host, own_cap, vert_cap, nullptr, plan_out, nullptr);
 }
 
-int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[24]) {
+int tfem_ring_plan_sizes(const void *plan_handle, int64_t layout[32]) {
   using namespace tfem;
   if (!plan_handle || !layout) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
   ring_layout(*static_cast<const RingPlan *>(plan_handle), layout);
@@ -951,7 +1071,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   // the arrays, each cut into pieces for the threads; the padding between them and the 64 spare
   // bytes at the end are zero
   struct Part { int64_t off; const void *src; int64_t bytes; };
-  const Part parts[8] = {
+  const Part parts[10] = {
       {layout[8], p->desc.data(), int64_t(p->desc.size()) * 4},
       {layout[9], p->rows.data(), int64_t(p->rows.size()) * 4},
       {layout[10], p->rowstart.data(), int64_t(p->rowstart.size()) * 4},
@@ -960,6 +1080,8 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
       {layout[16], p->tile_elems.data(), int64_t(p->tile_elems.size()) * 4},
       {layout[20], p->tile_tverts.data(), int64_t(p->tile_tverts.size()) * 4},
       {layout[22], p->long_rows.data(), int64_t(p->long_rows.size()) * 4},
+      {layout[24], p->chain_order.data(), int64_t(p->chain_order.size()) * 4},
+      {layout[26], p->hand_in.data(), int64_t(p->hand_in.size()) * 2},
   };
   for (const Part &part : parts) {
     const int64_t padded = (part.bytes + 15) & ~int64_t(15);

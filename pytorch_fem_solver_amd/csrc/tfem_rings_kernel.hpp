@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "tfem_common.hpp"
 #include "tfem_rowkit.hpp"
@@ -47,6 +48,11 @@ struct RingArgs {
                         // only -- a second table of 3 Q doubles does not fit the scalar registers and
                         // came back from its spill lanes with two v_readlane per use)
   unsigned off_tverts;  // packed local vertex triples of the tiles' elements (source programs)
+  // source programs: the launch walks positions [u_first, u_first + n_tiles) of the plan's chain
+  // order (off_chain: position -> tile), a workgroup takes chain_len consecutive positions;
+  // off_hin: per owned row the local id its vertex has in the previous tile of the block (uint16)
+  unsigned off_chain, off_hin;
+  int chain_len, u_first;
   int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
                   // source-value loads, 64 no element-id loads, 128 no g staging, 256 stamps
@@ -414,6 +420,7 @@ __device__ __forceinline__ void ring_load_rec(ring_rsrc_t r, unsigned byte, Ring
 // wave-uniform index (the plan is immutable during the launch: constant address space).
 struct RingDesc {
   int vert_off, n_vert, row_off, n_own, row0, row1, gid0, rs0, elem_off, n_elem, elem_mode, tvert_off;
+  int n_tv;  // elements the tile evaluates itself (source programs)
 };
 constexpr int kRingElemRuns = 8;  // desc[18] = 1: the tile's elements are <= 8 runs of consecutive ids
 
@@ -421,7 +428,7 @@ template <bool CHUNK>
 __device__ __forceinline__ RingDesc ring_desc(const unsigned char *plan, unsigned off_desc, int tile,
                                               int wave) {
   ring_const_i32 d = (ring_const_i32)(uintptr_t)(plan + off_desc + 80u * unsigned(tile));
-  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17], d[18], d[19]};
+  RingDesc r{d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], 0, 0, d[16], d[17], d[18] & 0xFF, d[19], d[18] >> 8};
   if (CHUNK) {
     r.gid0 = d[8 + wave];
     r.rs0 = d[12 + wave];
@@ -525,11 +532,28 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   const int xcd = blockIdx.x & 7;
   const int j0 = blockIdx.x >> 3;
   const int stride = gridDim.x >> 3;
+  // SRC: positions of the plan's chain order instead of tile numbers.  Blocks of chain_len
+  // positions (aligned to multiples of chain_len in the plan's order, whatever range the launch
+  // takes: the plan hands shares over inside such blocks) are dealt to the XCDs round-robin; a
+  // workgroup takes the positions of a block one after the other.
+  const int clen = SRC ? a.chain_len : 1;
+  const int u_end = a.u_first + a.n_tiles;
+  const int block0 = SRC ? a.u_first / clen : 0;
   auto tile_at = [&](int k) {
-    const int j = j0 + k * stride;
-    const int g = a.xcd_interleave;
-    const int t = g ? ((j / g) * 8 + xcd) * g + j % g : xcd * per + j;
-    return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
+    if constexpr (SRC != 0) {
+      // the workgroup of the launch's first block starts inside it when the range does
+      const int k2 = k + ((xcd == 0 && j0 == 0) ? a.u_first - block0 * clen : 0);
+      const int kb = k2 / clen, ki = k2 - kb * clen;
+      const int u = (block0 + (j0 + kb * stride) * 8 + xcd) * clen + ki;
+      if (u >= u_end) return -1;
+      ring_const_i32 order = (ring_const_i32)(uintptr_t)(a.plan + a.off_chain);
+      return __builtin_amdgcn_readfirstlane(order[u]);
+    } else {
+      const int j = j0 + k * stride;
+      const int g = a.xcd_interleave;
+      const int t = g ? ((j / g) * 8 + xcd) * g + j % g : xcd * per + j;
+      return __builtin_amdgcn_readfirstlane((j < per && t < a.n_tiles) ? t : -1);
+    }
   };
   const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
   const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
@@ -540,12 +564,18 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   constexpr unsigned kNone = 0x3FFFFFFu;  // row / vertex index behind every array: loads give 0
   if (FQ && tid < 4)  // the spare entries slots without a triangle read (times a zero determinant)
     gtab[3 * a.lds_elem + tid] = T(0);
-  // SRC: the same LDS region holds the load-vector accumulators, one per OWNED row (the sums of
-  // halo vertices would never be read: their shares are not added at all), double-buffered by
-  // tile parity (zeroed here; the other buffer again in every phase D)
-  T *faccbuf = gtab;
+  // SRC: the same LDS region holds the load-vector accumulators: THREE buffers (tile number modulo
+  // 3) of one sum per tile-LOCAL vertex, halo included, + one entry that stays zero.  A tile adds
+  // every share of every element it evaluates to the sum of the element's vertex -- no test, no
+  // table.  A row takes its own sum from its tile's buffer and, when the tile before it in the chain
+  // block evaluated elements of its fan (an element shared by consecutive tiles of a block is
+  // evaluated by the earlier one only), what that tile summed for its vertex from the PREVIOUS
+  // tile's buffer (plan: hand_in, the vertex's local id there).  A buffer is zeroed two tiles
+  // after it was filled: behind the barrier that ends the iteration of the last tile reading it.
+  const int acc_stride = a.lds_vert + 2;
+  T *accs = gtab;  // [3][acc_stride]
   if (SRC)
-    for (int i = tid; i < 2 * kRingBlock; i += kRingBlock) faccbuf[i] = T(0);
+    for (int i = tid; i < 3 * acc_stride; i += kRingBlock) accs[i] = T(0);
 
   // SRC: the program, one operation per lane, for the whole launch
   SrcLanes<T> prog;
@@ -560,6 +590,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   unsigned gid_own = 0, gid_halo = 0;        // vertex ids of the tile whose coordinates load next
   unsigned gid_own_ld = 0, gid_halo_ld = 0;  // ... and of the tile after it
   T own_ld[2], halo_ld[2];
+  unsigned hin = 0xFFFFu, hin_ld = 0xFFFFu;  // hand-in of this lane's current row, of the next tile's
 
   // vertex ids of a tile: the lane's own row vertex and halo vertex number tid.  With
   // consecutive-vertex tiles the own id is arithmetic on the descriptor.
@@ -634,53 +665,83 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     }
   };
   // SRC: the packed local vertex ids of the tile's elements (zero-filled past the last one)
-  auto load_tverts = [&](const RingDesc &d, unsigned (&tv)[SRC ? kRingElemPerLane : 1]) {
+  // Which lanes take which elements of a tile's table ROTATES over the waves from tile to tile
+  // (`rot` = number of the tile in the workgroup's sequence): wave w takes the elements
+  // ((w + rot) & 3) * 64 + lane + 256 j.  A table of ~520 elements holds 8 in its third round, which
+  // one wave sees; wave w of every workgroup sits on SIMD w, so without the rotation SIMD 0 would run
+  // three rounds for every tile while the others run two.
+  auto load_tverts = [&](const RingDesc &d, unsigned (&tv)[SRC ? kRingElemPerLane : 1], int rot) {
     if (!SRC) return;
+    const int vtid = (((wave + rot) & (kRingWaves - 1)) << 6) + lane;
 #pragma unroll
     for (int j = 0; j < kRingElemPerLane; ++j) {
-      const int l = tid + j * kRingBlock;
+      const int l = vtid + j * kRingBlock;
       tv[SRC ? j : 0] = __builtin_amdgcn_raw_buffer_load_b32(
-          r_plan, a.off_tverts + (l < d.n_elem ? unsigned(d.tvert_off + l) : kNone) * 4u, 0, kStreamLoadNT);
+          r_plan, a.off_tverts + (l < d.n_tv ? unsigned(d.tvert_off + l) : kNone) * 4u, 0, kStreamLoadNT);
     }
   };
   // SRC: det_T g[T][i], g[T][i] = sum_q f(x_q) l_i(q) w_q / 2, of the tile's elements from the
   // tile's coordinates in LDS (basis.py:90-91: x_q = bar(q)^T X), added to the accumulators of
   // the elements' vertices in LDS (element form: no slot codes, nothing per fan slot)
-  auto compute_g = [&](const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1], const T *xyc, T *dst) {
-    if constexpr (SRC == 2) {
-      if (TFEM_SRC_ABL & 16) return;
-      if (wave * 64 >= d.n_elem) return;  // wave-uniform: nothing for this wave in any round
-      constexpr int kNE = (TFEM_SRC_ABL & 1) ? 2 : kRingElemPerLane;
-      unsigned codes[kNE];
+  // one share det_T g[T][i] -> the accumulator the tile's table names for local vertex `lid`
+  auto add_share = [&](unsigned lid, T *acc, T v) {
+    if (TFEM_SRC_ABL & 4) {
+      if (v == T(-1.2345e300)) acc[lid] = v;
+    } else {
+      atomicAdd(acc + lid, v);
+    }
+  };
+  // NE elements per lane through the wide interpreter, then their shares
+  auto compute_g_wide = [&](auto ne_tag, const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1],
+                            const T *xyc, T *acc, int vtid) {
+    constexpr int kNE = decltype(ne_tag)::value;
+    unsigned codes[kNE];
 #pragma unroll
-      for (int j = 0; j < kNE; ++j) codes[j] = tv[SRC ? j : 0];
-      T fv[kNE * (QL > 0 ? QL : 1)];
-      src_run_wide<T, (QL > 0 ? QL : 1), kNE>(prog, xyc, codes, a.lam, fv);
+    for (int j = 0; j < kNE; ++j) codes[j] = tv[SRC ? j : 0];
+    T fv[kNE * (QL > 0 ? QL : 1)];
+    src_run_wide<T, (QL > 0 ? QL : 1), kNE>(prog, xyc, codes, a.lam, fv);
 #pragma unroll
-      for (int j = 0; j < kNE; ++j) {
-        const int l = tid + j * kRingBlock;
-        if (l < d.n_elem) {
-          const unsigned code = codes[j];
-          T x0, y0, x1, y1, x2, y2;
-          lds_xy(xyc, code & 0x3FFu, x0, y0);
-          lds_xy(xyc, (code >> 10) & 0x3FFu, x1, y1);
-          lds_xy(xyc, (code >> 20) & 0x3FFu, x2, y2);
-          const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-          T fw[QL > 0 ? QL : 1];
+    for (int j = 0; j < kNE; ++j) {
+      const int l = vtid + j * kRingBlock;
+      if (l < d.n_tv) {
+        const unsigned code = codes[j];
+        T x0, y0, x1, y1, x2, y2;
+        lds_xy(xyc, code & 0x3FFu, x0, y0);
+        lds_xy(xyc, (code >> 10) & 0x3FFu, x1, y1);
+        lds_xy(xyc, (code >> 20) & 0x3FFu, x2, y2);
+        const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+        T fw[QL > 0 ? QL : 1];
 #pragma unroll
-          for (int q = 0; q < QL; ++q) fw[q] = fv[j * (QL > 0 ? QL : 1) + q] * a.hw[q];
+        for (int q = 0; q < QL; ++q) fw[q] = fv[j * (QL > 0 ? QL : 1) + q] * a.hw[q];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            T g = T(0);
+        for (int i = 0; i < 3; ++i) {
+          T g = T(0);
 #pragma unroll
-            for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
-            const unsigned lid = (code >> (10 * i)) & 0x3FFu;
-            if (TFEM_SRC_ABL & 4) {
-              if (det * g == T(-1.2345e300)) dst[lid] = g;
-            } else if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
-          }
+          for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
+          add_share((code >> (10 * i)) & 0x3FFu, acc, det * g);
         }
       }
+    }
+  };
+  // SRC: det_T g[T][i], g[T][i] = sum_q f(x_q) l_i(q) w_q / 2, of the elements the tile evaluates
+  // from the tile's coordinates in LDS (basis.py:90-91: x_q = bar(q)^T X), added to the
+  // accumulators of the elements' vertices in LDS (element form: no slot codes, nothing per fan
+  // slot).  Lane `tid` takes the elements tid, tid + 256, tid + 512 of the tile's table; a wave
+  // runs the interpreter on as many of them as ITS lanes have (wave-uniform): of a tile's ~520
+  // elements the third round holds 8, which only wave 0 sees.
+  auto compute_g = [&](const RingDesc &d, const unsigned (&tv)[SRC ? kRingElemPerLane : 1], const T *xyc,
+                       T *acc, int rot) {
+    if (TFEM_SRC_ABL & 16) return;
+    const int vwave = (wave + rot) & (kRingWaves - 1);
+    const int vtid = (vwave << 6) + lane;
+    // rounds of this wave: elements vwave * 64 + 256 j + lane < n_tv
+    const int rounds = (d.n_tv - vwave * 64 + kRingBlock - 1) / kRingBlock;
+    if (rounds <= 0) return;  // wave-uniform
+    if constexpr (SRC == 2) {
+      if ((rounds >= 3 || (TFEM_SRC_ABL & 32)) && !(TFEM_SRC_ABL & 1))
+        compute_g_wide(std::integral_constant<int, 3>{}, d, tv, xyc, acc, vtid);
+      else
+        compute_g_wide(std::integral_constant<int, 2>{}, d, tv, xyc, acc, vtid);
     } else if constexpr (SRC == 1) {
       // the loop is not unrolled (one copy of the interpreter): every pass takes entry 0 and
       // rotates the array -- a register array indexed by the loop counter would go to scratch
@@ -689,8 +750,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       for (int j = 0; j < kRingElemPerLane; ++j) codes[j] = tv[SRC ? j : 0];
 #pragma unroll 1
       for (int j = 0; j < kRingElemPerLane; ++j) {
-        if (j * kRingBlock + wave * 64 >= d.n_elem) break;  // wave-uniform
-        const int l = tid + j * kRingBlock;
+        if (j >= rounds) break;  // wave-uniform
+        const int l = vtid + j * kRingBlock;
         const unsigned code = codes[0];
 #pragma unroll
         for (int r = 0; r + 1 < kRingElemPerLane; ++r) codes[r] = codes[r + 1];
@@ -705,10 +766,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
           yq[q] = (a.lam[0][q] * y0 + a.lam[1][q] * y1) + a.lam[2][q] * y2;
         }
         src_run<T, (QL > 0 ? QL : 1)>(prog, xq, yq, fv);
-        if (l < d.n_elem) {
-          // signed determinant in the element's own vertex order (element_tri.py:139); the
-          // element's three shares go to the accumulators of its vertices (ds_add_f64; the
-          // halo vertices' sums are never read)
+        if (l < d.n_tv) {
+          // signed determinant in the element's own vertex order (element_tri.py:139)
           const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
           T fw[QL > 0 ? QL : 1];
 #pragma unroll
@@ -718,8 +777,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
             T g = T(0);
 #pragma unroll
             for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
-            const unsigned lid = (code >> (10 * i)) & 0x3FFu;
-            if (lid < unsigned(d.n_own)) atomicAdd(dst + lid, det * g);  // halo sums are never read
+            add_share((code >> (10 * i)) & 0x3FFu, acc, det * g);
           }
         }
       }
@@ -748,6 +806,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       ring_load_xy<T>(r_coords, g_own, own_ld[0], own_ld[1]);
       ring_load_xy<T>(r_coords, g_halo, halo_ld[0], halo_ld[1]);
     }
+    if (SRC)  // local id of the row's vertex in the previous tile of the chain block (0xFFFF: none)
+      hin_ld = __builtin_amdgcn_raw_buffer_load_b16(r_plan, a.off_hin + row * 2u, 0, 0);
   };
   auto park = [&](const RingDesc &d, T *dst) {
     const int r = d.row0 + lane;
@@ -774,7 +834,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   load_tile(dc, gid_own, gid_halo);
   load_fq(dc, eid);
-  load_tverts(dc, tev_ld);
+  load_tverts(dc, tev_ld, 0);
   if (t_n >= 0) {
     load_ids(dn, gid_own_ld, gid_halo_ld);
     load_eids(dn, eid_ld);
@@ -783,6 +843,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   park(dc, xy);
   park_g(dc, gtab);
   rec = rec_ld;
+  hin = hin_ld;
   rowstart = rowstart_ld;
   gid_row = gid_own;
 #pragma unroll
@@ -803,6 +864,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   }
 #endif
   int cur = 0;
+  int a_cur = 0, a_prev = 2, a_next = 1;  // accumulator buffers of this tile, the one before, the one after
 #ifdef TFEM_SRC_TIMING
   const bool timing = a.stamps != nullptr;  // developer build: phase stamps of the source-program launch
 #else
@@ -819,7 +881,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       if (t_n >= 0) {
         load_tile(dn, gid_own, gid_halo);
         load_fq(dn, eid);
-        load_tverts(dn, tev_ld);
+        load_tverts(dn, tev_ld, k + 1);
         if (t_nn >= 0) {
           load_ids(dnn, gid_own_ld, gid_halo_ld);
           load_eids(dnn, eid_ld);
@@ -831,7 +893,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       // ---- G ---- source values of tile k (its coordinates are complete).  Before A: the
       // registers of tile k+1's loads are not live while the program runs (3 workgroups per CU)
       if (TFEM_SRC_PRIO & 1) __builtin_amdgcn_s_setprio(0);
-      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, faccbuf + cur * kRingBlock);
+      compute_g(dc, tev, xy + cur * 2 * a.lds_vert, accs + a_cur * acc_stride, k);
       if (TFEM_SRC_PRIO & 1) __builtin_amdgcn_s_setprio(3);
       // (the barrier behind G stands in front of the rows' read of their sums: the next tile's
       // loads and the rows' own arithmetic need nothing of G)
@@ -891,7 +953,8 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     if (SRC) {  // the row's sum is complete behind the barrier: one LDS read
       if (!(TFEM_SRC_ABL & 2)) ring_lds_barrier();
       const int my_row = dc.row0 + lane;
-      facc = faccbuf[cur * kRingBlock + (my_row < dc.row1 ? my_row : 0)];
+      const unsigned from = (hin & 0xFFFFu) == 0xFFFFu ? unsigned(a.lds_vert) : (hin & 0xFFFFu);  // lds_vert: the zero
+      facc = accs[a_cur * acc_stride + (my_row < dc.row1 ? my_row : a.lds_vert)] + accs[a_prev * acc_stride + from];
     }
     if (FQ) {
       const T *g = gtab;
@@ -918,9 +981,9 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     if (timing) t4 = ring_stamp();
     // ---- D ----
     if (SRC) {
-      // the accumulators the NEXT tile adds to (the other buffer): the rows of the previous tile
-      // read them before the last barrier E, the next tile's G starts behind the coming one
-      faccbuf[(cur ^ 1) * kRingBlock + tid] = T(0);
+      // the buffer the NEXT tile fills: the tile two back filled it, the rows of the tile before this
+      // one were its last readers (previous iteration, in front of its closing barrier)
+      for (int i = tid; i < acc_stride; i += kRingBlock) accs[a_next * acc_stride + i] = T(0);
     }
     if (t_n >= 0) {
       park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
@@ -972,6 +1035,7 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     }
     if (t_n < 0) break;
     rec = rec_ld;
+    hin = hin_ld;
     rowstart = rowstart_ld;
     gid_row = gid_own;
 #pragma unroll
@@ -982,6 +1046,12 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     for (int j = 0; j < (SRC ? kRingElemPerLane : 1); ++j) tev[j] = tev_ld[j];
     gid_own = gid_own_ld;
     gid_halo = gid_halo_ld;
+    {  // accumulator buffers: tile k + 1 fills what was the clean one
+      const int t = a_prev;
+      a_prev = a_cur;
+      a_cur = a_next;
+      a_next = t;
+    }
     // ---- E ----
     ring_lds_barrier();
     if (timing) {

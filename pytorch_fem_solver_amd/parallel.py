@@ -18,7 +18,7 @@ import torch
 
 from .meshgen import morton_order
 
-__all__ = ["partition_elements", "extract_shard", "InterfaceExchange"]
+__all__ = ["partition_elements", "extract_shard", "InterfaceExchange", "ShardedSteps"]
 
 
 def partition_elements(vertices, triangles, world, order="morton"):
@@ -134,12 +134,12 @@ class InterfaceExchange:
         head = (_native.ptr(vals), _native.ptr(flat_f), buf.element_size(), _native.ptr(self.k_idx),
                 _native.ptr(self.k_pos), self.k_idx.numel(), _native.ptr(self.f_idx),
                 _native.ptr(self.f_pos), self.f_idx.numel(), _native.ptr(buf))
-        keep = (vals, flat_f)  # noqa: F841  (the pointers above point into them)
+        keep = (self, vals, flat_f, self.k_idx, self.k_pos, self.f_idx, self.f_pos, buf)  # what `head` points into
         device, current_stream = buf.device, torch.cuda.current_stream
         from ctypes import c_void_p
 
         def run(fn, args):
-            def call(stream=None):
+            def call(stream=None, _keep=keep):  # the callables keep the tensors alive
                 handle = (stream if stream is not None else current_stream(device)).cuda_stream
                 status = fn(*args, c_void_p(handle))
                 if status:
@@ -269,3 +269,124 @@ class InterfaceExchange:
         cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)  # noqa: E731
         return cls(cat(k_idx), cat(k_pos), cat(f_idx), cat(f_pos), max(world - 1, 0) * per_k,
                    max(world - 1, 0) * nvx, engine.device, engine.dtype, group)
+
+
+class ShardedSteps:
+    """The repeated step of a sharded run (BASELINE config 4): every rank assembles K and f of its
+    element range into one of `depth` preallocated (vals, f) pairs and sums the entries it shares
+    with other ranks -- pack, ONE all-reduce of the packed interface buffer (RCCL), unpack.
+
+    The assembly launches follow each other on the assembly stream; the exchange of step i runs on
+    the exchange stream beside the launch of step i + 1 (steps are independent: the pair of step i
+    is written again by step i + depth, which waits for its exchange on the device).  The host side
+    of a step is four enqueue calls and a collective; over RCCL `capture()` records `graph_steps`
+    consecutive steps -- both streams, the collectives included -- into ONE HIP graph, so that a
+    step costs the host a fraction of a graph launch (tools/time_step_host_overhead.py).
+
+    interface_first: the ring plan lists the tiles owning shared vertices first
+    (engine.set_priority_vertices before the plan is built); a step then launches those on the
+    exchange stream, in front of its exchange, and the rest on the assembly stream (the shared rows
+    reach the other ranks a launch earlier; two launches per step)."""
+
+    def __init__(self, engine, exchange, alpha, beta, source=None, fq=None, depth=3, interface_first=False):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.engine, self.exchange, self.depth = engine, exchange, int(depth)
+        device = engine.device
+        nnz = int(engine.csr_structure()[1].shape[0])
+        self.pairs = [(torch.empty(nnz, dtype=engine.dtype, device=device),
+                       torch.empty(engine.n_dofs, dtype=engine.dtype, device=device)) for _ in range(self.depth)]
+        self.main = torch.cuda.Stream(device=device)
+        self.comm = torch.cuda.Stream(device=device, priority=-1)
+        self.main.wait_stream(torch.cuda.current_stream(device))  # behind the set-up (plan copies ...)
+        self.interface_first = bool(interface_first)
+        self.launches = []
+        for pair in self.pairs:
+            pack, unpack = exchange.prepared(*pair)
+            if self.interface_first:
+                first = engine.prepared_system(alpha, beta, pair, fq=fq, source=source, tiles="priority")
+                rest = engine.prepared_system(alpha, beta, pair, fq=fq, source=source, tiles="rest")
+            else:
+                first, rest = None, engine.prepared_system(alpha, beta, pair, fq=fq, source=source)
+            self.launches.append((first, rest, pack, unpack))
+        self.counter = 0
+        self.done = [None] * self.depth      # end of the exchange that last used the pair (eager steps)
+        self.graph, self.graph_steps = None, 0
+        self.mode, self.capture_error = "eager", None
+
+    # one step's work on the two streams; `done`: per pair the event of its last exchange
+    def _enqueue(self, slot, done):
+        first, rest, pack, unpack = self.launches[slot]
+        main, comm = self.main, self.comm
+        if done[slot] is not None:
+            main.wait_event(done[slot])      # the pair is free: its exchange of `depth` steps ago is over
+        fork = torch.cuda.Event()
+        fork.record(main)
+        comm.wait_event(fork)                # (also what makes the exchange stream part of a capture)
+        if first is not None:
+            first(comm)                      # rows of the shared vertices, in front of their exchange
+            rest(main)
+        else:
+            rest(main)
+            assembled = torch.cuda.Event()
+            assembled.record(main)
+            comm.wait_event(assembled)
+        pack(comm)
+        with torch.cuda.stream(comm):
+            self.dist.all_reduce(self.exchange.buffer, op=self.dist.ReduceOp.SUM, group=self.exchange.group)
+        unpack(comm)
+        if first is not None:                # the pair is complete when BOTH streams are through
+            rest_done = torch.cuda.Event()
+            rest_done.record(main)
+            comm.wait_event(rest_done)
+        done[slot] = torch.cuda.Event()
+        done[slot].record(comm)
+
+    def capture(self, graph_steps=None):
+        """Record `graph_steps` steps (a multiple of depth; default 2 * depth) into one HIP graph.
+        Returns True when replays are in use from now on; on any failure the eager steps stay."""
+        steps = int(graph_steps or 2 * self.depth)
+        if steps % self.depth:
+            raise ValueError("graph_steps must be a multiple of depth")
+        self.sync()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the process group's watchdog thread may query its events meanwhile
+            with torch.cuda.graph(graph, stream=self.main, capture_error_mode="thread_local"):
+                done = [None] * self.depth
+                for i in range(steps):
+                    self._enqueue(i % self.depth, done)
+                self.main.wait_stream(self.comm)  # join: the capture ends on one stream
+        except Exception as exc:  # noqa: BLE001 -- whatever the capture refuses: eager steps
+            self.capture_error = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize(self.engine.device)
+            return False
+        self.graph, self.graph_steps, self.mode = graph, steps, "graph"
+        return True
+
+    def run(self, n):
+        """Enqueue n steps; returns the pair of the last one (complete after sync())."""
+        n = int(n)
+        while n > 0:
+            if self.graph is not None and self.counter % self.depth == 0 and n >= self.graph_steps:
+                if any(e is not None for e in self.done):
+                    self.main.wait_stream(self.comm)
+                    self.done = [None] * self.depth
+                with torch.cuda.stream(self.main):
+                    self.graph.replay()
+                self.counter += self.graph_steps
+                n -= self.graph_steps
+                continue
+            if self.graph is not None and all(e is None for e in self.done):
+                # behind a replay everything is complete at the END of the assembly stream's queue
+                self.comm.wait_stream(self.main)
+            self._enqueue(self.counter % self.depth, self.done)
+            self.counter += 1
+            n -= 1
+        return self.pairs[(self.counter - 1) % self.depth]
+
+    def sync(self):
+        """Host wait for everything enqueued so far (both streams)."""
+        self.main.synchronize()
+        self.comm.synchronize()

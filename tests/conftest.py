@@ -43,6 +43,37 @@ def scaled_error(got, want):
     )
 
 
+def rowwise_error(got, want, rowptr=None, scale=None):
+    """Entry-wise bound, scaled per ROW: max_i max_j |got_ij - want_ij| / s_i.
+
+    The tolerance north_star states (rtol 1e-12) is entry-wise; a plain entry-wise ratio is
+    ill-posed where entries cancel to zero, a norm-wise bound (scaled_error) lets a large row hide
+    an error in a small one.  Here every entry is measured against the scale of its own row:
+    s_i = max_j |want_ij| for CSR values (`rowptr` given; the row's diagonal for a stiffness
+    matrix), or the caller's `scale` (vectors: the sum of the magnitudes of the element shares
+    that make up entry i).  Rows with s_i = 0 must be reproduced exactly."""
+    got = np.asarray(got, dtype=np.float64).ravel()
+    want = np.asarray(want, dtype=np.float64).ravel()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    diff = np.abs(got - want)
+    if rowptr is not None:
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        starts = rowptr[:-1][np.diff(rowptr) > 0]
+        row_of = np.repeat(np.arange(rowptr.size - 1), np.diff(rowptr))
+        s = np.zeros(rowptr.size - 1)
+        s[np.diff(rowptr) > 0] = np.maximum.reduceat(np.abs(want), starts)
+        s = s[row_of]
+    else:
+        s = np.abs(np.asarray(scale, dtype=np.float64).ravel())
+        assert s.shape == want.shape
+    zero = s == 0.0
+    if zero.any() and diff[zero].max() != 0.0:
+        return float("inf")
+    if zero.all():
+        return 0.0
+    return float((diff[~zero] / s[~zero]).max())
+
+
 @pytest.fixture
 def golden():
     return load_golden

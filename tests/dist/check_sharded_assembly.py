@@ -35,6 +35,9 @@ def main():
     p.add_argument("--points", type=int, default=20000)
     p.add_argument("--grid", type=int, default=96)
     p.add_argument("--out-dir", default=None, help="rank r writes rank<r>.json there (stdout lines of ranks interleave)")
+    p.add_argument("--stepper", choices=("inline", "sharded", "sharded-first", "graph", "graph-first"), default="inline",
+                   help="inline: the two-stream step spelled out here; sharded / graph: parallel.ShardedSteps, eager "
+                   "or recorded into HIP graphs (graph needs --backend nccl), -first: interface tiles first")
     args = p.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
@@ -63,7 +66,13 @@ def main():
     eng = basis._engine
     csr = eng.csr_structure()
     rowptr, colind = csr[0].cpu().numpy(), csr[1].cpu().numpy()
-    if args.layout == "partition":
+    if world == 1:
+        # one rank (the RCCL rehearsal on a one-GPU box): nothing is shared, so the exchange gets an
+        # arbitrary set of entries to carry through pack -> all-reduce over one rank -> unpack
+        k_idx, f_idx = np.arange(0, colind.shape[0], 7)[:5000], np.arange(0, nv, 3)[:2000]
+        ex = parallel.InterfaceExchange(k_idx, np.arange(k_idx.size), f_idx, np.arange(f_idx.size), k_idx.size,
+                                        f_idx.size, device, torch.float64)
+    elif args.layout == "partition":
         ex = parallel.InterfaceExchange.from_partition(whole, order, bounds, rank, rowptr, colind, l2g, device, torch.float64)
     else:
         ex = parallel.InterfaceExchange.for_strips(mesh_np, rank, world, eng)
@@ -71,17 +80,34 @@ def main():
     program = forms.trace(load_form, basis, (), {}).coefficient.program()
     n_pri, n_all = eng.tile_range("priority")[1], eng.tile_range("all")[1]
     nnz = int(colind.shape[0])
-    out = (torch.full((nnz,), float("nan")), torch.full((nv,), float("nan")))
-    comm = torch.cuda.Stream(device=device, priority=-1)
-    for _ in range(3):  # the step of bench.py, three times into the same buffers
+    mode = "inline"
+    if args.stepper == "inline":
+        out = (torch.full((nnz,), float("nan")), torch.full((nv,), float("nan")))
+        comm = torch.cuda.Stream(device=device, priority=-1)
+        for _ in range(3):  # the two-stream step, three times into the same buffers
+            torch.cuda.current_stream().wait_stream(comm)
+            with torch.cuda.stream(comm):
+                comm.wait_stream(torch.cuda.current_stream())
+                eng.assemble_system(1.0, 0.5, source=program, out=out, tiles="priority")
+                ex.reduce(*out)
+            eng.assemble_system(1.0, 0.5, source=program, out=out, tiles="rest")
         torch.cuda.current_stream().wait_stream(comm)
-        with torch.cuda.stream(comm):
-            comm.wait_stream(torch.cuda.current_stream())
-            eng.assemble_system(1.0, 0.5, source=program, out=out, tiles="priority")
-            ex.reduce(*out)
-        eng.assemble_system(1.0, 0.5, source=program, out=out, tiles="rest")
-    torch.cuda.current_stream().wait_stream(comm)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    else:  # the steps of bench.py: rotating pairs, exchange beside the next launch, optionally as HIP graphs
+        steps = parallel.ShardedSteps(eng, ex, 1.0, 0.5, source=program, depth=3,
+                                      interface_first=args.stepper.endswith("-first") and 0 < n_pri < n_all)
+        for pair in steps.pairs:
+            pair[0].fill_(float("nan"))
+            pair[1].fill_(float("nan"))
+        steps.run(4)
+        if args.stepper.startswith("graph"):
+            assert steps.capture(6), steps.capture_error
+        out = steps.run(6 + 6 + 2)  # replays and eager steps, in this order and mixed
+        steps.sync()
+        mode = steps.mode
+        for pair in steps.pairs:  # every pair holds the same complete result (K bit for bit)
+            assert torch.equal(pair[0], out[0])
+            assert float((pair[1] - out[1]).abs().max()) <= 1e-14 * float(out[1].abs().max())
 
     # the whole mesh on this GPU (every rank for itself)
     gbasis = tf.Basis(tf.MeshTri(triangulation=whole), tf.ElementTri(1, 3))
@@ -99,7 +125,7 @@ def main():
     # entry is shared; entries of interior rows of OTHER ranks do not exist in this pattern
     err_v = float((out[0] - want_v).abs().max() / want_v.abs().max())
     err_f = float((out[1] - want_f).abs().max() / want_f.abs().max())
-    result = json.dumps({"rank": rank, "world": world, "layout": args.layout, "n_local_vertices": int(nv),
+    result = json.dumps({"rank": rank, "world": world, "layout": args.layout, "n_local_vertices": int(nv), "mode": mode,
                          "priority_tiles": n_pri, "tiles": n_all, "interface_entries": int(ex.n_matrix + ex.n_vector),
                          "err_values": err_v, "err_vector": err_f})
     if args.out_dir:

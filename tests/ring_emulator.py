@@ -29,6 +29,55 @@ def decode_rows(rows, slots):
     return {"id": ids, "flag": flag, "pos": pos, "k": k.astype(np.int64), "dpos": dpos.astype(np.int64)}
 
 
+def source_load_vector(plan, coords, source, lam, lamw, tiles=None, conn=None):
+    """The load vector of a source program as the SRC launches form it: the tiles in CHAIN ORDER,
+    blocks of chain_len positions per workgroup; a tile evaluates the elements of its own table
+    (tile_tverts, desc[18] >> 8 of them) from its tile-local coordinates and adds the three shares
+    det_T g[T][i] to the sums of the elements' tile-LOCAL vertices, halo included; a row takes its
+    own sum and what the tile before it in the block summed for its vertex (hand_in: the vertex's
+    local id there).  tiles = (first, count): positions of the chain order."""
+    from oracle.assembly_oracle import source_program_eval
+
+    desc = plan["desc"].reshape(-1, 20)
+    order, clen, hand_in = plan["chain_order"], int(plan["chain_len"]), plan["hand_in"]
+    n = desc.shape[0]
+    assert sorted(order.tolist()) == list(range(n)) and clen >= 1
+    u0, u1 = (0, n) if tiles is None else (tiles[0], tiles[0] + tiles[1])
+    fvec = np.full(coords.shape[0], np.nan)
+    for u in range(u0, u1):
+        d = desc[order[u]]
+        vert_off, n_vert, row_off, n_own, n_elem, n_tv, tv_off = (
+            int(d[0]), int(d[1]), int(d[2]), int(d[7]), int(d[17]), int(d[18]) >> 8, int(d[19]))
+        assert n_tv <= n_elem and n_tv <= 768
+        gid = plan["vert_gid"][vert_off:vert_off + n_vert]
+        xy = coords[gid]
+        tv = plan["tile_tverts"][tv_off:tv_off + n_tv].astype(np.int64)
+        local = np.stack([tv & 0x3FF, (tv >> 10) & 0x3FF, (tv >> 20) & 0x3FF], axis=1).reshape(-1, 3)
+        assert n_tv == 0 or local.max() < n_vert
+        if conn is not None and n_tv:  # every table entry is an element, in the element's own local order
+            have = {tuple(r) for r in conn[np.nonzero(np.isin(conn, gid[:n_own]).any(axis=1))[0]].tolist()}
+            assert all(tuple(r) in have for r in gid[local].tolist())
+        cx, cy = xy[local][..., 0], xy[local][..., 1]
+        xq = (np.outer(cx[:, 0], lam[0]) + np.outer(cx[:, 1], lam[1])) + np.outer(cx[:, 2], lam[2])
+        yq = (np.outer(cy[:, 0], lam[0]) + np.outer(cy[:, 1], lam[1])) + np.outer(cy[:, 2], lam[2])
+        fq_tile = source_program_eval(source[0], source[1], xq, yq) if n_tv else np.zeros((0, lam.shape[1]))
+        det = (cx[:, 1] - cx[:, 0]) * (cy[:, 2] - cy[:, 0]) - (cx[:, 2] - cx[:, 0]) * (cy[:, 1] - cy[:, 0])
+        acc = np.zeros(n_vert)
+        for i in range(3):
+            np.add.at(acc, local[:, i], det * (fq_tile @ lamw[i]))
+        hin = hand_in[row_off:row_off + n_own].astype(np.int64)
+        first_of_block = u % clen == 0 or u == u0 or u == plan.get("n_priority", 0)
+        if first_of_block:  # nobody hands anything to the first tile of a block or of a launch's range
+            assert np.all(hin == 0xFFFF)
+        else:
+            # the previous tile's sums are indexed by ITS local ids: the ids name this tile's vertices
+            assert np.array_equal(prev_gid[hin[hin != 0xFFFF]], gid[:n_own][hin != 0xFFFF])
+        handed = np.where(hin != 0xFFFF, prev_acc[np.minimum(hin, prev_acc.size - 1)], 0.0) if not first_of_block else 0.0
+        fvec[gid[:n_own]] = acc[:n_own] + handed
+        prev_acc, prev_gid = acc, gid
+    return fvec
+
+
 def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=None, lamw=None,
                   conn=None, source=None, lam=None, tiles=None):
     """Returns (vals, writes, covered[, f]): CSR values of stiff_w-weighted stiffness + mass,
@@ -48,6 +97,7 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
     covered = 0
     long_seen = {}
     fvec = np.full(coords.shape[0], np.nan) if (fq is not None or source is not None) else None
+    fsource = source_load_vector(plan, coords, source, lam, lamw, tiles, conn) if source is not None else None
     ewords = (12 * slots + 31) // 32  # packed 12-bit slot codes
     row_ecodes = plan["row_ecodes"].reshape(-1, ewords)
     if tiles is not None:
@@ -67,7 +117,7 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         xy = coords[gid]
         rec = decode_rows(rows[row_off:row_off + n_own], slots)
         elem_off, n_elem = int(d[16]), int(d[17])
-        if int(d[18]):  # <= 8 runs of consecutive ids: first ids, then list positions they end at
+        if int(d[18]) & 0xFF:  # <= 8 runs of consecutive ids: first ids, then list positions they end at
             first, upto = plan["tile_elems"][elem_off:elem_off + 8], plan["tile_elems"][elem_off + 8:elem_off + 16]
             pos = np.arange(n_elem)
             tile_elems = first[0] + pos
@@ -77,25 +127,9 @@ def run_ring_plan(plan, coords, nnz, stiff_w=0.5, mass_d=0.0, mass_o=0.0, fq=Non
         else:
             tile_elems = plan["tile_elems"][elem_off:elem_off + n_elem]
         assert np.all(np.diff(tile_elems) > 0) and (n_elem <= 768 or not plan["elems_staged"])
-        tvert_off = int(d[19])
-        tv = plan["tile_tverts"][tvert_off:tvert_off + n_elem].astype(np.int64)
-        assert tv.shape[0] == n_elem
-        local = np.stack([tv & 0x3FF, (tv >> 10) & 0x3FF, (tv >> 20) & 0x3FF], axis=1)
-        assert n_elem == 0 or local.max() < n_vert
-        if conn is not None:  # the element's vertices, in the element's own local order
-            assert np.array_equal(gid[local], conn[tile_elems])
         facc_tile = None
-        if source is not None:
-            # element form: f at the element's points from the tile-local coordinates, the three
-            # shares det_T g[T][i] added to the accumulators of the element's local vertices
-            cx, cy = xy[local][..., 0], xy[local][..., 1]  # (n_elem, 3)
-            xq = (np.outer(cx[:, 0], lam[0]) + np.outer(cx[:, 1], lam[1])) + np.outer(cx[:, 2], lam[2])
-            yq = (np.outer(cy[:, 0], lam[0]) + np.outer(cy[:, 1], lam[1])) + np.outer(cy[:, 2], lam[2])
-            fq_tile = source_program_eval(source[0], source[1], xq, yq)
-            det = (cx[:, 1] - cx[:, 0]) * (cy[:, 2] - cy[:, 0]) - (cx[:, 2] - cx[:, 0]) * (cy[:, 1] - cy[:, 0])
-            facc_tile = np.zeros(n_vert)
-            for i in range(3):
-                np.add.at(facc_tile, local[:, i], det * (fq_tile @ lamw[i]))
+        if source is not None:  # element form, in the order of the SRC launches: source_load_vector
+            facc_tile = fsource[gid]
         rowstart = plan["rowstart"][row_off:row_off + n_own]
         for w, (a, b) in enumerate(zip(wave_start[:-1], wave_start[1:])):
             if b > a:  # what the consecutive-vertex kernel takes from the descriptor

@@ -48,6 +48,42 @@ def test_sharded_assembly_with_interface_tiles_first(world, layout, tmp_path):
     assert len({r["interface_entries"] for r in ranks}) == 1  # one global interface numbering
 
 
+@pytest.mark.parametrize("world,layout,stepper", [(2, "partition", "sharded"), (3, "partition", "sharded-first"),
+                                                  (2, "strips", "sharded")])
+def test_sharded_steps_of_the_bench(world, layout, stepper, tmp_path):
+    """parallel.ShardedSteps (the steps bench.py --gpus N times): rotating pairs, the exchange of a
+    step beside the next step's launch; every pair ends with the operator of the whole mesh."""
+    ranks = _run(world, tmp_path, "--layout", layout, "--stepper", stepper)
+    for r in ranks:
+        assert r["err_values"] <= 1e-12 and r["err_vector"] <= 1e-12 and r["mode"] == "eager", r
+
+
+@pytest.mark.parametrize("stepper", ["graph", "graph-first"])
+def test_steps_recorded_into_hip_graphs_over_rccl_one_rank(stepper, tmp_path):
+    """The HIP-graph form of the steps needs RCCL (gloo cannot be captured) and the test box has one
+    GPU: ONE rank over RCCL, the exchange carrying an arbitrary set of entries through pack ->
+    all-reduce -> unpack inside the captured graph; replays and eager steps mixed; against the
+    operator of the whole mesh."""
+    ranks = _run(1, tmp_path, "--layout", "partition", "--backend", "nccl", "--stepper", stepper)
+    assert ranks[0]["mode"] == "graph" and ranks[0]["err_values"] <= 1e-12 and ranks[0]["err_vector"] <= 1e-12, ranks
+
+
+def test_bench_default_scaling_is_config_4_and_one_rank_over_rccl_takes_graphs(tmp_path):
+    """bench.py's N > 1 defaults: --scaling strong (BASELINE config 4).  And the whole N > 1 machinery
+    with ONE rank over RCCL (torch.distributed.run, world size 1 is treated as N = 1 by bench.py, so
+    the check of the graph mode over RCCL is tests/dist/check_sharded_assembly.py above)."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8"]
+        args = bench.parse()
+    finally:
+        sys.argv = old
+    assert args.scaling == "strong" and args.step_mode == "auto" and not args.interface_first
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_runs_with_two_ranks(scaling, tmp_path):
     """The driver's multi-GPU command line (bench.py under torch.distributed.run), two ranks on the
@@ -65,6 +101,8 @@ def test_bench_runs_with_two_ranks(scaling, tmp_path):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == scaling
-    assert out["value"] > 0 and out["config"]["interface_tiles_first"] is not None
+    assert out["value"] > 0 and out["config"]["interface_tiles_first"] is None  # one launch per step by default
+    assert out["config"]["world_size"] == 2 and out["config"]["backend"] == "gloo" and len(out["config"]["devices"]) == 2
+    assert out["config"]["step_mode"] == "eager" and out["config"]["host_us_per_step"] > 0
     n_elems = 2 * 256 * 256
     assert out["config"]["elements_per_gpu"] == (n_elems if scaling == "weak" else n_elems // 2)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, mesh_from_golden, scaled_error
+from conftest import load_golden, mesh_from_golden, rowwise_error, scaled_error
 from oracle import assembly_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -116,6 +116,12 @@ def test_p1_against_golden(fixture, orders):
             assert scaled_error(dense.cpu(), d[tag + name]) <= TOL, (name, order)
             csr = basis.integrate_bilinear_form(form, layout="csr")
             assert scaled_error(csr.to_dense().cpu(), d[tag + name]) <= TOL
+            # entry by entry against the scale of the entry's own row (rtol 1e-12 of north_star);
+            # the pattern is the oracle's, from the connectivity alone
+            rowptr, colind, _ = orc.csr_pattern(d["in_triangles"], d["in_vertices"].shape[0])
+            assert np.array_equal(csr.crow_indices.cpu().numpy(), rowptr) and np.array_equal(csr.col_indices.cpu().numpy(), colind)
+            rows = np.repeat(np.arange(rowptr.size - 1), np.diff(rowptr))
+            assert rowwise_error(csr.values.cpu(), d[tag + name][rows, colind], rowptr) <= TOL, (name, order)
         f = basis.integrate_linear_form(load)
         assert f.shape == d[tag + "f_load"].shape
         assert scaled_error(f.cpu(), d[tag + "f_load"]) <= TOL
@@ -629,6 +635,16 @@ def test_ring_plan_variant_with_long_rows(numbering, monkeypatch):
     fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, "load")
     assert scaled_error(f.cpu(), orc.assemble_linear(fl, mesh_np["triangles"], nv)) <= TOL
     assert not plan["fq_ok"]  # source VALUES do not take this plan
+    # a launch over a PART of the tiles would leave long rows unwritten (they have one launch over
+    # all of them): refused, by the engine and by the library
+    with pytest.raises(NotImplementedError):
+        eng.tile_range("rest")
+    got = torch.zeros(colind.shape[0])
+    status = eng.lib.tfem_p1_assemble_rings_range(
+        eng._inputs()["coords"].data_ptr(), 8, nv, 3, 1.0, 0.0, plan["blob"].data_ptr(),
+        plan["layout"].ctypes.data, got.data_ptr(), colind.shape[0], None, None, eng.n_elems, None,
+        0, max(1, plan["n_tiles"] // 2), torch.cuda.current_stream().cuda_stream)
+    assert status != 0 and "long rows" in eng.lib.tfem_last_error().decode()
 
 
 def test_engine_picks_the_tile_kernel_for_a_numbering_without_locality():
@@ -717,14 +733,23 @@ def test_bench_workload_against_c_oracle_at_full_size(n):
     fq_np = orc.source_sin_sin(pts)[..., 0]
     vals, f = eng.assemble_system(1.0, 0.0, torch.tensor(fq_np))
     assert eng.kernel_name() == "k_p1_rings"
-    rowptr, colind, slots = (t.cpu().numpy() for t in eng.csr_structure())
+    # the CSR pattern and the element -> entry map the expected values go through are the ORACLE's
+    # (numpy, from the connectivity alone), and the product's pattern has to be that pattern
+    rowptr, colind, slots = orc.csr_pattern(tris, nv)
+    got_rowptr, got_colind, _ = (t.cpu().numpy() for t in eng.csr_structure())
+    assert np.array_equal(got_rowptr, rowptr) and np.array_equal(got_colind, colind)
     k_local, f_local = c_oracle.p1_local(verts, tris, 3, 1.0, 0.0, fq_np)
     want_vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
     want_f = c_oracle.scatter_vector(f_local, tris, nv)
+    f_scale = c_oracle.scatter_vector(np.abs(f_local), tris, nv)  # what every entry is a sum of
     assert scaled_error(vals.cpu(), want_vals) <= TOL
     assert scaled_error(f.cpu(), want_f) <= TOL
+    # entry by entry, every entry against the scale of its own row (north_star: rtol 1e-12)
+    assert rowwise_error(vals.cpu(), want_vals, rowptr) <= TOL
+    assert rowwise_error(f.cpu(), want_f, scale=f_scale) <= TOL
     # K alone (row-form kernel, the launch the roofline target is quoted on)
-    assert scaled_error(eng.bilinear(1.0, 0.0).cpu(), want_vals) <= TOL
+    k_alone = eng.bilinear(1.0, 0.0).cpu()
+    assert scaled_error(k_alone, want_vals) <= TOL and rowwise_error(k_alone, want_vals, rowptr) <= TOL
     # the integration points the HIP geometry kernel hands to user callables
     assert scaled_error(basis.integration_points.cpu().reshape(-1, 4, 2), pts) <= TOL
 

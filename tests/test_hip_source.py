@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, mesh_from_golden, scaled_error
+from conftest import load_golden, mesh_from_golden, rowwise_error, scaled_error
 from oracle import assembly_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -149,6 +149,33 @@ def test_traced_load_vector_against_golden(fixture, orders):
         assert called == [True], "the load form did not take the source-program launch"
         assert f.shape == d[f"out_q{order}_f_load"].shape
         assert scaled_error(f.cpu(), d[f"out_q{order}_f_load"]) <= TOL
+
+
+@pytest.mark.parametrize(
+    "fixture,order",
+    [("p1_square_n8.npz", 3), ("p1_square_n8.npz", 4), ("p1_square_n5_clockwise.npz", 3), ("p1_delaunay_170.npz", 3)],
+)
+def test_public_fused_call_is_one_launch_and_matches_golden(fixture, order):
+    """Basis.assemble_system(a, l): both forms of tests/test_assembly.py:68-93 in ONE launch
+    (k_p1_rings with the source program inside), K_stiffness_mass and f_load of the fixtures."""
+    d = load_golden(fixture)
+    basis = tf().Basis(tf().MeshTri(triangulation=mesh_from_golden(d)), tf().ElementTri(1, order))
+    eng = basis._engine
+    calls = []
+    original = eng._assemble_rings
+    eng._assemble_rings = lambda *a, **k: calls.append(k.get("source") is not None) or original(*a, **k)
+    K, f = basis.assemble_system(lambda b: b.v_grad @ b.v_grad.mT + b.v @ b.v.mT, load)
+    assert calls == [True], "not one fused launch"
+    assert K.shape == d[f"out_q{order}_K_stiffness_mass"].shape and f.shape == d[f"out_q{order}_f_load"].shape
+    assert scaled_error(K.cpu(), d[f"out_q{order}_K_stiffness_mass"]) <= TOL
+    assert scaled_error(f.cpu(), d[f"out_q{order}_f_load"]) <= TOL
+    # a tensor coefficient and a form outside the vocabulary: the same pair through two calls
+    K2, f2 = basis.assemble_system(lambda b: b.v_grad @ b.v_grad.mT + b.v @ b.v.mT,
+                                   lambda b: rhs(*torch.split(b.integration_points.clone(), 1, dim=-1)) * b.v)
+    assert scaled_error(K2.cpu(), K.cpu()) <= 1e-15 and scaled_error(f2.cpu(), d[f"out_q{order}_f_load"]) <= TOL
+    Kc, fc = basis.assemble_system(lambda b: b.v @ b.v_grad[..., [0]].mT, load)  # the non-symmetric form
+    assert scaled_error(Kc.cpu(), d[f"out_q{order}_K_convection_x"]) <= TOL
+    assert scaled_error(fc.cpu(), d[f"out_q{order}_f_load"]) <= TOL
 
 
 def test_traced_load_vector_float32_and_cpu_home():
@@ -313,11 +340,20 @@ def test_full_size_traced_system_against_c_oracle():
     vals, f = eng.assemble_system(1.0, 0.0, source=program)
     assert eng.kernel_name() == "k_p1_rings" and eng._rings_take_source()
     fq_np = orc.source_sin_sin(c_oracle.points(verts, tris, 3))[..., 0]
-    _, colind, slots = (t.cpu().numpy() for t in eng.csr_structure())
+    rowptr, colind, slots = orc.csr_pattern(tris, nv)  # the oracle's pattern, not the product's
+    got_rowptr, got_colind, _ = (t.cpu().numpy() for t in eng.csr_structure())
+    assert np.array_equal(got_rowptr, rowptr) and np.array_equal(got_colind, colind)
     k_local, f_local = c_oracle.p1_local(verts, tris, 3, 1.0, 0.0, fq_np)
-    assert scaled_error(vals.cpu(), c_oracle.scatter_csr(k_local, slots, colind.shape[0])) <= TOL
+    want_vals = c_oracle.scatter_csr(k_local, slots, colind.shape[0])
+    assert scaled_error(vals.cpu(), want_vals) <= TOL
+    assert rowwise_error(vals.cpu(), want_vals, rowptr) <= TOL
     want_f = c_oracle.scatter_vector(f_local, tris, nv)
     assert scaled_error(f.cpu(), want_f) <= TOL
+    assert rowwise_error(f.cpu(), want_f, scale=c_oracle.scatter_vector(np.abs(f_local), tris, nv)) <= TOL
+    # the public fused call: one launch for both forms, the same numbers
+    K_api, f_pub = basis.assemble_system(lambda b: b.v_grad @ b.v_grad.mT, load, layout="csr")
+    assert rowwise_error(K_api.values.cpu(), want_vals, rowptr) <= TOL
+    assert scaled_error(f_pub.cpu().view(-1), want_f) <= TOL
     # size-independent properties of the load vector: sum f = integral of f over the square
     # (= 2 pi^2 (2 / pi)^2 = 8 up to the quadrature error of the order-3 rule on this mesh)
     assert abs(float(f.sum()) - float(want_f.sum())) <= 1e-11 * 8.0

@@ -12,6 +12,7 @@ import torch
 from conftest import REPO, load_golden, mesh_from_golden, scaled_error
 from oracle import assembly_oracle as orc
 from plan_emulator import run_plan
+import ring_emulator
 from ring_emulator import run_ring_plan
 from p2rows_emulator import run_p2_plan
 
@@ -275,6 +276,51 @@ def test_ring_plan_is_a_valid_exact_cover(kind, form, monkeypatch):
     _, _, _, fsrc = run_ring_plan(plan, mesh["vertices"], colind.shape[0], w, md, mo, lamw=lamw,
                                   conn=mesh["triangles"], source=_SIN_SIN_PROGRAM, lam=bary.T)
     assert scaled_error(fsrc, want_f) <= 1e-13
+
+
+@pytest.mark.parametrize("kind", ["structured", "delaunay", "delaunay_shuffled", "clockwise_mixed"])
+@pytest.mark.parametrize("chain", [2, 3, 5])
+def test_chain_blocks_evaluate_every_element_share_once(kind, chain, monkeypatch):
+    """Source-program launches walk the tiles in chain order (tests/ring_emulator.source_load_vector):
+    inside a block of `chain` positions an element in the fans of two consecutive tiles is in the
+    table of the earlier tile only, which hands the later tile's shares over; the load vector is
+    the oracle's, over the whole order and over the two ranges a sharded step launches (tiles
+    owning flagged vertices / the rest), and fewer elements are evaluated than without blocks."""
+    from pytorch_fem_solver_amd.basis.engine import ring_plan_host, symbolic_host
+
+    mesh = _ring_case(kind)
+    nv = mesh["vertices"].shape[0]
+    rowptr, colind, _ = symbolic_host(mesh["triangles"], nv)
+    weights = np.asarray(orc.gauss_rule(3)[1]).reshape(-1)
+    bary = np.asarray(orc.barycentric_coordinates(orc.gauss_rule(3)[0])).reshape(-1, 3)
+    lamw = (bary * (0.5 * weights)[:, None]).T
+    fl, _ = orc.p1_assemble(mesh["vertices"], mesh["triangles"], 3, "load")
+    want_f = orc.assemble_linear(fl, mesh["triangles"], nv).reshape(-1)
+    flags = np.zeros(nv, dtype=bool)
+    flags[np.random.default_rng(11).choice(nv, 9, replace=False)] = True
+    caps = dict(own_cap=64, vert_cap=160)
+    monkeypatch.setenv("TFEM_RING_CHAIN", "1")
+    alone = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, **caps)
+    assert alone["chain_len"] == 1 and np.all(alone["hand_in"] == 0xFFFF)
+    d1 = alone["desc"].reshape(-1, 20)
+    assert np.array_equal(d1[:, 18] >> 8, d1[:, 17])  # no blocks: every tile evaluates all of its elements
+    monkeypatch.setenv("TFEM_RING_CHAIN", str(chain))
+    for priority in (None, flags):
+        plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=priority, **caps)
+        assert plan["chain_len"] == chain
+        d = plan["desc"].reshape(-1, 20)
+        assert (d[:, 18] >> 8).sum() < d1[:, 17].sum() and plan["tile_tverts"].size == (d[:, 18] >> 8).sum()
+        n_pri, n_tiles = plan["n_priority"], plan["n_tiles"]
+        order = plan["chain_order"]
+        assert sorted(order[:n_pri].tolist()) == list(range(n_pri))  # the flagged tiles first in both orders
+        args = (plan, mesh["vertices"], _SIN_SIN_PROGRAM, bary.T, lamw)
+        f_all = ring_emulator.source_load_vector(*args, conn=mesh["triangles"])
+        assert scaled_error(f_all, want_f) <= 1e-13
+        if priority is not None:
+            first = ring_emulator.source_load_vector(*args, tiles=(0, n_pri))
+            rest = ring_emulator.source_load_vector(*args, tiles=(n_pri, n_tiles - n_pri))
+            assert not np.any(np.isnan(first[flags])) and np.all(np.isnan(first) != np.isnan(rest))
+            assert np.array_equal(np.where(np.isnan(first), rest, first), f_all)
 
 
 @pytest.mark.parametrize("kind", ["structured", "delaunay"])
@@ -797,7 +843,8 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
     """The once-per-mesh builders (CSR pattern, slot map, ring plan) are multi-threaded
     (csrc/tfem_threads.hpp): 1, 3 and the default number of threads give identical bytes, and the
     bytes are the ones the sequential builder produced for these meshes (digests taken from that
-    build before the builders were restructured)."""
+    build before the builders were restructured; retaken in round 3 when the plan gained the chain
+    order, the carry maps and per-tile element tables -- the arrays of round 2 are unchanged)."""
     import hashlib
 
     from pytorch_fem_solver_amd import meshgen
@@ -805,10 +852,10 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
 
     delaunay = meshgen.delaunay_square(30000, 3)
     cases = {
-        "S300": (meshgen.unit_square(300, 0.25, 0), "edd742215b8f66d5", "9b34763e1a02eab9"),
+        "S300": (meshgen.unit_square(300, 0.25, 0), "5a04cc60528a1596", "9b34763e1a02eab9"),
         "Dmorton": (meshgen.permute_mesh(delaunay, vertex_order=meshgen.morton_order(delaunay["vertices"])),
-                    "d3d38becab193360", None),
-        "Dnative": (delaunay, "d789ebac29155b24", None),
+                    "64a75dbc3cf7c485", None),
+        "Dnative": (delaunay, "3af7e622040c38a6", None),
     }
     saved = os.environ.get("TFEM_HOST_THREADS")
     saved_long = os.environ.get("TFEM_RING_LONG")

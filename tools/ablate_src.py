@@ -50,7 +50,10 @@ def child(n):
 
     t_sys = timed(lambda: eng.assemble_system(1.0, 0.0, source=program, out=out))
     t_f = timed(lambda: eng.load_source(program))
-    print(f"{os.environ.get('TFEM_VARIANT', 'product'):20s} per_cu={os.environ.get('TFEM_RINGS_PER_CU', '-'):2s} K+f {t_sys:7.1f} us   f only {t_f:7.1f} us", flush=True)
+    one = forms.compile_program(("c", 1.0))
+    t_one = timed(lambda: eng.assemble_system(1.0, 0.0, source=one, out=out))
+    print(f"{os.environ.get('TFEM_VARIANT', 'product'):20s} per_cu={os.environ.get('TFEM_RINGS_PER_CU', '-'):2s} K+f {t_sys:7.1f} us   "
+          f"f only {t_f:7.1f} us   K+f(const) {t_one:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":

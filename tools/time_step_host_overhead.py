@@ -1,26 +1,44 @@
-"""Host time of the multi-GPU step of bench.py without the collective itself, on ONE GPU with a
-small mesh (the launches are short: what remains is Python + ctypes + stream bookkeeping per step).
-The all-reduce adds its own host time (RCCL enqueue) on top."""
+"""Host time per step of a sharded run (bench.py --gpus N: parallel.ShardedSteps), on ONE GPU with
+ONE rank over RCCL and a small mesh -- the launches are short, so what the wall clock shows per
+step is the host: Python + ctypes + stream bookkeeping + the collective's enqueue for the eager
+steps, a fraction of one graph launch for the steps recorded into HIP graphs.
+
+    python tools/time_step_host_overhead.py [n] [steps per graph]
+"""
 import math
 import os
 import sys
 import time
 
+import numpy as np
 import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import pytorch_fem_solver_amd as tf  # noqa: E402
 from pytorch_fem_solver_amd import meshgen, parallel  # noqa: E402
 from pytorch_fem_solver_amd.basis import forms  # noqa: E402
 
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29531")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 torch.set_default_dtype(torch.float64)
 torch.set_default_device("cuda")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+graph_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 mesh_np = meshgen.structured_rectangle(n, n, 0.0, 1.0, 1.0, 2.0, jitter=0.25, seed=0)
 basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(1, 3))
 eng = basis._engine
-ex = parallel.InterfaceExchange.for_strips(mesh_np, 1, 3, eng)
-eng.set_priority_vertices(ex.shared_vertices(mesh_np["vertices"].shape[0]))
+nv = mesh_np["vertices"].shape[0]
+nnz = int(eng.csr_structure()[1].shape[0])
+# what a strip between two other strips shares: its first and last grid row (entries of the row's
+# vertices and of the horizontal edges), carried through the all-reduce of this one rank
+rows = np.concatenate([np.arange(n + 1), nv - 1 - np.arange(n + 1)])
+rowptr = eng.csr_structure()[0].cpu().numpy()
+k_idx = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in rows])
+ex = parallel.InterfaceExchange(k_idx, np.arange(k_idx.size), rows, np.arange(rows.size), k_idx.size, rows.size,
+                                eng.device, torch.float64)
 
 
 def load(b):
@@ -29,56 +47,31 @@ def load(b):
 
 
 program = forms.trace(load, basis, (), {}).coefficient.program()
-nnz = int(eng.csr_structure()[1].shape[0])
-out = (torch.empty(nnz), torch.empty(eng.n_dofs))
-comm = torch.cuda.Stream(priority=-1)
 
 
-def step():
-    with torch.cuda.stream(comm):
-        eng.assemble_system(1.0, 0.0, source=program, out=out, tiles="priority")
-        ex.pack(*out)
-        ex.unpack(*out)
-        done = torch.cuda.Event()
-        done.record(comm)
-    eng.assemble_system(1.0, 0.0, source=program, out=out, tiles="rest")
-    return done
-
-
-launch_priority = eng.prepared_system(1.0, 0.0, out, source=program, tiles="priority")
-launch_rest = eng.prepared_system(1.0, 0.0, out, source=program, tiles="rest")
-pack, unpack = ex.prepared(*out)
-
-
-def prepared_step():
-    with torch.cuda.stream(comm):
-        launch_priority()
-        pack()
-        unpack()
-        done = torch.cuda.Event()
-        done.record(comm)
-    launch_rest()
-    return done
-
-
-def timed(fn):
-    for _ in range(200):
-        fn()
-    torch.cuda.synchronize()
+def timed(steps, label, count=3000):
+    steps.run(300)
+    steps.sync()
     t0 = time.perf_counter()
-    for _ in range(2000):
-        torch.cuda.current_stream().wait_event(fn())
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 2000 * 1e6
+    steps.run(count)
+    host = time.perf_counter() - t0
+    steps.sync()
+    wall = time.perf_counter() - t0
+    print(f"{label:58s} host {host / count * 1e6:6.1f} us per step   wall {wall / count * 1e6:6.1f} us per step", flush=True)
 
 
-print(f"prepared launches: {timed(prepared_step):.1f} us per step")
-for _ in range(200):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(2000):
-    torch.cuda.current_stream().wait_event(step())
-torch.cuda.synchronize()
-print(f"S({n}) strip, {eng.n_elems} elements: {(time.perf_counter() - t0) / 2000 * 1e6:.1f} us per step "
-      f"(two range launches, pack, unpack, events; no collective)")
+print(f"S({n}) strip, {eng.n_elems} elements, interface buffer {ex.nbytes} B, one rank over RCCL")
+for first in (False, True):
+    if first:
+        basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(1, 3))
+        eng = basis._engine
+        eng.set_priority_vertices(ex.shared_vertices(nv))
+    steps = parallel.ShardedSteps(eng, ex, 1.0, 0.0, source=program, depth=3, interface_first=first)
+    what = "interface tiles first (two launches)" if first else "one launch per step"
+    timed(steps, f"eager, {what}")
+    ok = steps.capture(graph_steps)
+    if not ok:
+        print("capture failed:", steps.capture_error)
+        continue
+    timed(steps, f"HIP graphs of {graph_steps} steps, {what}")
+dist.destroy_process_group()
