@@ -639,19 +639,28 @@ def main():
                 + ("" if world == 1 else "; N > 1: kernel_ms = wall clock of the timed region / steps (two streams and a "
                    "collective per step), achieved = this rank's algorithmic bytes over it"),
                 "stiffness_only": {
-                    "kernel_ms": k_only_ms,
-                    "cold_ms": float(np.median(cold)),
-                    "cold_after_reads_ms": float(np.median(cold_read)),
+                    # the launch BASELINE.json's 60 % target is quoted on.  `frac` is the CACHE-FREE figure:
+                    # every launch behind 512 MB of unrelated reads, so that neither the L2s nor the 256 MB
+                    # memory-side cache (Infinity Cache) hold any of its ~200 MB read set.  Back to back into
+                    # one buffer (what a caller re-assembling on a fixed mesh sees) that read set survives
+                    # in the memory-side cache from launch to launch: `frac_back_to_back`; FETCH_SIZE
+                    # counts those hits as fetched bytes, so `traffic` is fabric traffic, not HBM traffic.
+                    # `frac_behind_writes`: every launch behind 512 MB of unrelated WRITES, whose
+                    # write-back (up to 256 MB of dirty lines) shares the HBM with the launch.
+                    "kernel_ms": float(np.median(cold_read)),
+                    "frac": algo_k / (float(np.median(cold_read)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "achieved": algo_k / (float(np.median(cold_read)) * 1e-3) / 1e9,
+                    "state": "cold caches: behind 512 MB of unrelated reads",
+                    "back_to_back_ms": k_only_ms,
+                    "frac_back_to_back": algo_k / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "behind_writes_ms": float(np.median(cold)),
+                    "frac_behind_writes": algo_k / (float(np.median(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": profile["k_only"].get("traffic"),
                     "algorithmic_bytes_per_launch": algo_k,
-                    "achieved": algo_k / (k_only_ms * 1e-3) / 1e9,
-                    "frac": algo_k / (k_only_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "frac_cold": algo_k / (float(np.median(cold)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "frac_cold_after_reads": algo_k / (float(np.median(cold_read)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 },
             },
         }
-        for key, obj, ms in (("fused", line["roofline"], k_ms), ("k_only", line["roofline"]["stiffness_only"], k_only_ms)):
+        for key, obj, ms in (("fused", line["roofline"], k_ms), ("k_only", line["roofline"]["stiffness_only"], k_only_ms)):  # traffic was counted back to back
             for extra in ("kernel_ms_rocprofv3", "valu_utilisation"):
                 if extra in profile[key]:
                     obj[extra] = profile[key][extra]

@@ -24,7 +24,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include "tfem_common.hpp"
 #include "tfem_rowkit.hpp"
@@ -54,8 +56,18 @@ struct P2RowArgs {
 
 // entries r[0..6) of one row of the element block in the frame whose edge vectors are e1, e2
 template <typename T, bool MASS>
+__device__ __forceinline__ void p2_block_row(const T (&ca)[6], const T (&cb)[6], const T (&cd)[6], const T (&cm)[6],
+                                             T q1, T q2, T p, T cross, uint32_t flag, T (&r)[6]);
+
+template <typename T, bool MASS>
 __device__ __forceinline__ void p2_block_row(const P2RowArgs<T> &a, T q1, T q2, T p, T cross,
                                              uint32_t flag, T (&r)[6]) {
+  p2_block_row<T, MASS>(a.ca, a.cb, a.cd, a.cm, q1, q2, p, cross, flag, r);
+}
+
+template <typename T, bool MASS>
+__device__ __forceinline__ void p2_block_row(const T (&ca)[6], const T (&cb)[6], const T (&cd)[6], const T (&cm)[6],
+                                             T q1, T q2, T p, T cross, uint32_t flag, T (&r)[6]) {
   // flag: 0 no triangle (all zero), 1 frame = (e1, e2) as given, 2 frame = (e2, e1)
   const T c = flag_weight<T>(T(1), flag) * fast_rcp<T>(flag ? cross : T(1));  // 1 / det or 0
   const T g11 = c * (flag == 2u ? q1 : q2);
@@ -64,15 +76,15 @@ __device__ __forceinline__ void p2_block_row(const P2RowArgs<T> &a, T q1, T q2, 
   const T det = flag_weight<T>(T(1), flag) * cross;
 #pragma unroll
   for (int m = 0; m < 6; ++m) {
-    T v = a.ca[m] * g11 + a.cb[m] * g12 + a.cd[m] * g22;
-    if (MASS) v = v + a.cm[m] * det;
+    T v = ca[m] * g11 + cb[m] * g12 + cd[m] * g22;
+    if (MASS) v = v + cm[m] * det;
     r[m] = v;
   }
 }
 
 // The wave's stage -> global memory: the wave's rows are consecutive DoFs, so stage index +
 // delta = CSR index.  Lane j of step u takes entries 128 u + 2 j and the next one.
-template <typename T, int MAXLEN>
+template <typename T, int MAXLEN, int AUX = 0>
 __device__ __forceinline__ void p2_store(const T *stage, int total, int delta, ring_rsrc_t r_vals) {
   const int lane = threadIdx.x & 63;
   constexpr int kSteps = (64 * MAXLEN + 127) / 128;
@@ -85,16 +97,16 @@ __device__ __forceinline__ void p2_store(const T *stage, int total, int delta, r
       if (128 * (u + 1) <= total || s0 + 1 < total) {
         if constexpr (sizeof(T) == 8) {
           const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, AUX);
         } else {
           __builtin_amdgcn_raw_buffer_store_b64(
-              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, 0);
+              ru32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r_vals, byte, 0, AUX);
         }
       } else if (s0 < total) {
         if constexpr (sizeof(T) == 8)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, v0), r_vals, byte, 0, AUX);
         else
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), r_vals, byte, 0, AUX);
       }
     }
   }
@@ -104,17 +116,19 @@ __device__ __forceinline__ void p2_store(const T *stage, int total, int delta, r
 // are not in the stage, so the CSR position of the rows behind them is further on.  `pre` =
 // stage index of the lane's row, `csr` = CSR offset of the lane's row, `is_long` marks the
 // holes: the stage is streamed out piece by piece between them.
+// [lane_lo, lane_hi): the lanes whose rows are in the stage (the persistent kernel stages a wave's
+// vertex rows in two halves); `pre` is relative to the first of them.
 template <typename T>
 __device__ __forceinline__ void p2_store_pieces(const T *stage, int total, int pre, int csr, bool is_long,
-                                                ring_rsrc_t r_vals) {
+                                                ring_rsrc_t r_vals, int lane_lo = 0, int lane_hi = 64) {
   const int lane = threadIdx.x & 63;
-  unsigned long long holes = __ballot(is_long);
-  int first_lane = 0;  // first lane of the current piece
+  unsigned long long holes = __ballot(is_long && lane >= lane_lo && lane < lane_hi);
+  int first_lane = lane_lo;  // first lane of the current piece
   for (;;) {
-    const int stop_lane = holes ? __builtin_ctzll(holes) : 64;  // the piece: lanes [first_lane, stop_lane)
-    if (first_lane < 64 && first_lane < stop_lane) {
+    const int stop_lane = holes ? __builtin_ctzll(holes) : lane_hi;  // the piece: lanes [first_lane, stop_lane)
+    if (first_lane < lane_hi && first_lane < stop_lane) {
       const int b = __builtin_amdgcn_readlane(pre, first_lane);
-      const int e = stop_lane < 64 ? __builtin_amdgcn_readlane(pre, stop_lane) : total;
+      const int e = stop_lane < lane_hi ? __builtin_amdgcn_readlane(pre, stop_lane) : total;
       const int delta = __builtin_amdgcn_readlane(csr, first_lane) - b;
       for (int s0 = b + lane; s0 < e; s0 += 64) {
         const unsigned byte = unsigned(s0 + delta) * unsigned(sizeof(T));
@@ -317,6 +331,305 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// ONE persistent launch for the vertex rows and the edge rows (TFEM_P2_PERSIST=1; the two launches
+// of k_p2_rows above are the default: see launch_p2_rows for the measurement).  Workgroups
+// stay resident and walk the unified tile list (vertex tiles, then edge tiles), dealt to the XCDs
+// in blocks of four tiles so that every XCD gets its share of both kinds.  Software pipeline as in
+// k_p1_rings (tfem_rings_kernel.hpp): iteration k issues the loads of tile k+1 (row record; the
+// coordinates of up to four tile-local vertices per lane by ids that arrived an iteration earlier)
+// and the vertex ids of tile k+2, evaluates the rows of tile k from xy[k & 1] in LDS, streams them
+// out through the wave's stage, waits ONCE for its loads (issued a whole row phase earlier), parks
+// the coordinates of tile k+1 in xy[(k+1) & 1] and passes one LDS barrier.  A wave's 64 vertex
+// rows (up to 22 entries each) go through the stage in four quarters of 16 rows, its edge rows in
+// two halves: 2.8 KB per wave instead of 11.3, so four workgroups fit a CU.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct P2AllArgs {
+  const T *coords;
+  const unsigned char *plan;
+  T *vals;
+  unsigned coords_bytes, plan_bytes, vals_bytes;
+  unsigned off_desc[2], off_rows[2], off_gid[2];  // [0] vertex tiles, [1] edge tiles
+  int n_tiles[2];
+  int lds_vert;  // local vertices of the largest tile of either kind, even
+  int nt_stores;  // developer switch (TFEM_P2_NT=1): non-temporal value stores
+  T ca[2][6], cb[2][6], cd[2][6], cm[2][6];
+};
+
+constexpr int kP2StageHalf = 16 * kP2VertexRowMax + 2;  // a QUARTER of a wave's vertex rows; >= 32 * kP2EdgeRowMax + 2
+constexpr int kP2LocalPerLane = 4;                      // <= 1024 local vertices per tile
+
+struct P2Desc {
+  int kind, vert_off, n_vert, row_off, n_own, row0, row1, rs0;
+};
+
+template <typename T>
+__device__ __forceinline__ P2Desc p2_desc(const P2AllArgs<T> &a, int tile, int wave) {
+  const int kind = tile >= a.n_tiles[0] ? 1 : 0;
+  ring_const_i32 d = (ring_const_i32)(uintptr_t)(a.plan + a.off_desc[kind] + 64u * unsigned(tile - (kind ? a.n_tiles[0] : 0)));
+  return P2Desc{kind, d[0], d[1], d[2], d[7], d[3 + wave], d[4 + wave], d[12 + wave]};
+}
+
+template <typename T, bool MASS>
+__global__ __launch_bounds__(kP2Block, 4) void k_p2_rows_all(const P2AllArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char p2_smem[];
+  T *xy = reinterpret_cast<T *>(p2_smem);  // [2][2 * lds_vert]
+  T *stage = xy + 4 * a.lds_vert;          // [waves][kP2StageHalf]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T *my_stage = stage + wave * kP2StageHalf;
+  const int n_all = a.n_tiles[0] + a.n_tiles[1];
+  const int per = (n_all + 31) / 32 * 4;  // tiles per XCD, whole blocks of four
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  auto tile_at = [&](int k) {
+    const int j = j0 + k * stride;
+    const int t = ((j >> 2) * 8 + xcd) * 4 + (j & 3);
+    return __builtin_amdgcn_readfirstlane((j < per && t < n_all) ? t : -1);
+  };
+  const ring_rsrc_t r_coords = ring_rsrc(a.coords, a.coords_bytes);
+  const ring_rsrc_t r_plan = ring_rsrc(a.plan, a.plan_bytes);
+  const ring_rsrc_t r_vals = ring_rsrc(a.vals, a.vals_bytes);
+  constexpr unsigned kNone = 0x3FFFFFFu;
+  const int n_local = (a.lds_vert + kP2Block - 1) / kP2Block;  // coordinate loads per lane (uniform)
+
+  uint32_t w[8], w_ld[8];
+  unsigned gid[kP2LocalPerLane], gid_ld[kP2LocalPerLane];
+  T c_ld[kP2LocalPerLane][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = w_ld[i] = 0u;
+#pragma unroll
+  for (int j = 0; j < kP2LocalPerLane; ++j) {
+    gid[j] = gid_ld[j] = 0u;
+    c_ld[j][0] = c_ld[j][1] = T(0);
+  }
+
+  auto load_ids = [&](const P2Desc &d, unsigned (&g)[kP2LocalPerLane]) {
+#pragma unroll
+    for (int j = 0; j < kP2LocalPerLane; ++j) {
+      if (j >= n_local) break;
+      const int l = tid + j * kP2Block;
+      g[j] = __builtin_amdgcn_raw_buffer_load_b32(
+          r_plan, a.off_gid[d.kind] + (l < d.n_vert ? unsigned(d.vert_off + l) : kNone) * 4u, 0, 0);
+    }
+  };
+  auto load_tile = [&](const P2Desc &d, const unsigned (&g)[kP2LocalPerLane]) {
+    const int r = d.row0 + lane;
+    const unsigned row = r < d.row1 ? unsigned(d.row_off + r) : kNone;
+    if (d.kind == 0) {
+      const unsigned byte = a.off_rows[0] + row * 32u;
+      const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, byte, 0, 0);
+      const ru32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_plan, byte + 16u, 0, 0);
+      w_ld[0] = v.x; w_ld[1] = v.y; w_ld[2] = v.z; w_ld[3] = v.w;
+      w_ld[4] = u.x; w_ld[5] = u.y; w_ld[6] = u.z; w_ld[7] = u.w;
+    } else {
+      const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_plan, a.off_rows[1] + row * 16u, 0, 0);
+      w_ld[0] = v.x; w_ld[1] = v.y; w_ld[2] = v.z; w_ld[3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < kP2LocalPerLane; ++j) {
+      if (j >= n_local) break;
+      ring_load_xy<T>(r_coords, g[j], c_ld[j][0], c_ld[j][1]);
+    }
+  };
+  auto park = [&](const P2Desc &d, T *dst) {
+#pragma unroll
+    for (int j = 0; j < kP2LocalPerLane; ++j) {
+      if (j >= n_local) break;
+      const int l = tid + j * kP2Block;
+      if (l < d.n_vert) {
+        dst[2 * l] = c_ld[j][0];
+        dst[2 * l + 1] = c_ld[j][1];
+      }
+    }
+  };
+
+  int t_c = tile_at(0);
+  if (t_c < 0) return;  // whole workgroup, before any barrier
+  int t_n = tile_at(1), t_nn = tile_at(2);
+  P2Desc dc = p2_desc(a, t_c, wave);
+  P2Desc dn = p2_desc(a, t_n >= 0 ? t_n : t_c, wave);
+  P2Desc dnn = p2_desc(a, t_nn >= 0 ? t_nn : t_c, wave);
+  load_ids(dc, gid);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  load_tile(dc, gid);
+  if (t_n >= 0) load_ids(dn, gid_ld);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  park(dc, xy);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = w_ld[i];
+#pragma unroll
+  for (int j = 0; j < kP2LocalPerLane; ++j) gid[j] = gid_ld[j];
+  __syncthreads();
+
+  int cur = 0;
+  for (int k = 0;; ++k) {
+    // ---- A: loads of tile k+1, vertex ids of tile k+2
+    if (t_n >= 0) {
+      load_tile(dn, gid);
+      if (t_nn >= 0) load_ids(dnn, gid_ld);
+    }
+    // ---- C: the only wait -- the loads of A were issued a whole row phase ago, the stores of the
+    // previous tile a whole iteration ago; D: coordinates of tile k+1 -> the other buffer.  Called
+    // by the row code between its arithmetic and its stores.
+    auto wait_and_park = [&]() {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (t_n >= 0) park(dn, xy + (cur ^ 1) * 2 * a.lds_vert);
+    };
+    // ---- B: rows of tile k
+    const T *xyc = xy + cur * 2 * a.lds_vert;
+    const int my_row = dc.row0 + lane;
+    const bool has_row = my_row < dc.row1;
+    if (dc.kind == 0) {
+      const int kk = int((w[2] >> 24) & 7u);
+      auto id = [&](int i) { return (w[i / 3] >> (10 * (i % 3))) & 0x3FFu; };
+      auto flag_of = [&](int i) { return (w[2] >> (10 + 2 * i)) & 3u; };
+      auto field = [&](int f) { return int((w[3 + f / 6] >> (5 * (f % 6))) & 31u); };
+      T xv, yv, px, py;
+      lds_xy(xyc, unsigned(has_row ? my_row : 0), xv, yv);
+      const uint32_t id0 = id(0);
+      lds_xy(xyc, id0, px, py);
+      T ecx = px - xv, ecy = py - yv;
+      T qc = ecx * ecx + ecy * ecy;
+      T diag = T(0), vcol[8], ecol[8], ocol[7];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vcol[i] = ecol[i] = T(0);
+      int n_tri = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const uint32_t idn = (i + 1 < 7 && i + 1 != kk) ? id(i + 1 < 7 ? i + 1 : 0) : id0;
+        lds_xy(xyc, idn, px, py);
+        const T enx = px - xv, eny = py - yv;
+        const T qn = enx * enx + eny * eny;
+        const T p = ecx * enx + ecy * eny;
+        const T cross = ecx * eny - ecy * enx;
+        const uint32_t flag = flag_of(i);  // 0 for every slot i >= k
+        n_tri += flag ? 1 : 0;
+        T r[6];
+        p2_block_row<T, MASS>(a.ca[0], a.cb[0], a.cd[0], a.cm[0], qc, qn, p, cross, flag, r);
+        const bool fwd = flag != 2u;
+        diag = diag + r[0];
+        vcol[i] = vcol[i] + (fwd ? r[1] : r[2]);
+        vcol[i + 1] = vcol[i + 1] + (fwd ? r[2] : r[1]);
+        ecol[i] = ecol[i] + (fwd ? r[3] : r[5]);
+        ecol[i + 1] = ecol[i + 1] + (fwd ? r[5] : r[3]);
+        ocol[i] = r[4];
+        ecx = enx;
+        ecy = eny;
+        qc = qn;
+      }
+      T wv = vcol[1], we = ecol[1];
+#pragma unroll
+      for (int j = 2; j <= 7; ++j) {
+        wv = kk == j ? vcol[j] : wv;
+        we = kk == j ? ecol[j] : we;
+      }
+      vcol[0] = vcol[0] + wv;
+      ecol[0] = ecol[0] + we;
+      const int len = kk > 0 ? 1 + 2 * kk + n_tri : 0;
+      const int incl = wave_inclusive_scan(len);
+      const int pre = incl - len;
+      const bool is_long = has_row && kk == 0 && (w[3] >> 31) != 0u;
+      const int true_len = is_long ? int(w[3] & 0x7FFFFFFFu) : len;
+      const bool any_long = __ballot(is_long) != 0ull;
+      const int csr = any_long ? dc.rs0 + wave_inclusive_scan(true_len) - true_len : 0;
+      // entries in front of the rows of lanes 16, 32, 48 and behind the last one
+      const int cut[5] = {0, __builtin_amdgcn_readlane(incl, 15), __builtin_amdgcn_readlane(incl, 31),
+                          __builtin_amdgcn_readlane(incl, 47), __builtin_amdgcn_readlane(incl, 63)};
+      constexpr int kSpare = kP2StageHalf - 2;
+      wait_and_park();  // ---- C, D: in front of this tile's stores (they get a whole iteration)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const bool mine = (lane >> 4) == pass;
+        const int base = cut[pass], count = cut[pass + 1] - cut[pass];
+        const int at = pre - base;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          my_stage[(mine && i < kk) ? at + field(i) : kSpare] = vcol[i];
+          my_stage[(mine && i < kk) ? at + field(7 + i) : kSpare] = ecol[i];
+          my_stage[(mine && i < kk && flag_of(i)) ? at + field(14 + i) : kSpare] = ocol[i];
+        }
+        my_stage[(mine && kk > 0) ? at + int(w[2] >> 27) : kSpare] = diag;
+        __builtin_amdgcn_wave_barrier();
+        if (!any_long) {  // 16 x 22 = 352 <= 64 x 6 entries
+          if (a.nt_stores)
+            p2_store<T, 6, kStreamNT>(my_stage, count, dc.rs0 + base, r_vals);
+          else
+            p2_store<T, 6>(my_stage, count, dc.rs0 + base, r_vals);
+        } else {
+          p2_store_pieces<T>(my_stage, count, at, csr, is_long, r_vals, 16 * pass, 16 * pass + 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      const bool has2 = (w[1] >> 10) & 1u;
+      const bool rev = (w[1] >> 11) & 1u;
+      T ax, ay, bx, by, cx, cy, dx, dy;
+      lds_xy(xyc, w[0] & 0x3FFu, ax, ay);
+      lds_xy(xyc, (w[0] >> 10) & 0x3FFu, bx, by);
+      lds_xy(xyc, (w[0] >> 20) & 0x3FFu, cx, cy);
+      lds_xy(xyc, w[1] & 0x3FFu, dx, dy);
+      T r[6], s[6];
+      {
+        const T e1x = bx - ax, e1y = by - ay, e2x = cx - ax, e2y = cy - ay;
+        p2_block_row<T, MASS>(a.ca[1], a.cb[1], a.cd[1], a.cm[1], e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y,
+                              e1x * e2x + e1y * e2y, e1x * e2y - e1y * e2x, has_row ? 1u : 0u, r);
+      }
+      {
+        const T ox = rev ? bx : ax, oy = rev ? by : ay;
+        const T tx = rev ? ax : bx, ty = rev ? ay : by;
+        const T e1x = tx - ox, e1y = ty - oy, e2x = dx - ox, e2y = dy - oy;
+        p2_block_row<T, MASS>(a.ca[1], a.cb[1], a.cd[1], a.cm[1], e1x * e1x + e1y * e1y, e2x * e2x + e2y * e2y,
+                              e1x * e2x + e1y * e2y, e1x * e2y - e1y * e2x, (has_row && has2) ? 1u : 0u, s);
+      }
+      const int len = has_row ? (has2 ? 9 : 6) : 0;
+      const int incl = wave_inclusive_scan(len);
+      const int pre = incl - len;
+      constexpr int kSpare = kP2StageHalf - 2;
+      const uint32_t w2 = w[2], w3 = w[3];
+      auto pos = [&](int f) { return int(((f < 8 ? w2 >> (4 * f) : w3) & 15u)); };
+      wait_and_park();  // ---- C, D
+      const int half = __builtin_amdgcn_readlane(incl, 31), total = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool on = has_row && (lane >> 5) == pass;
+        const int base = pass ? half : 0, count = pass ? total - half : half;
+        const int at = pre - base;
+        my_stage[on ? at + pos(0) : kSpare] = r[0] + (rev ? s[1] : s[0]);
+        my_stage[on ? at + pos(1) : kSpare] = r[1] + (rev ? s[0] : s[1]);
+        my_stage[on ? at + pos(2) : kSpare] = r[2];
+        my_stage[on ? at + pos(3) : kSpare] = r[3] + s[3];
+        my_stage[on ? at + pos(4) : kSpare] = r[4];
+        my_stage[on ? at + pos(5) : kSpare] = r[5];
+        my_stage[(on && has2) ? at + pos(6) : kSpare] = s[2];
+        my_stage[(on && has2) ? at + pos(7) : kSpare] = s[4];
+        my_stage[(on && has2) ? at + pos(8) : kSpare] = s[5];
+        __builtin_amdgcn_wave_barrier();
+        if (a.nt_stores)  // 32 x 9 = 288 <= 64 x 5 entries
+          p2_store<T, 5, kStreamNT>(my_stage, count, dc.rs0 + base, r_vals);
+        else
+          p2_store<T, 5>(my_stage, count, dc.rs0 + base, r_vals);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (t_n < 0) break;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = w_ld[i];
+#pragma unroll
+    for (int j = 0; j < kP2LocalPerLane; ++j) gid[j] = gid_ld[j];
+    // ---- E: xy[(k+1) & 1] is complete, nobody reads xy[k & 1] any more
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    t_c = t_n;
+    dc = dn;
+    t_n = t_nn;
+    dn = dnn;
+    t_nn = tile_at(k + 3);
+    if (t_nn >= 0) dnn = p2_desc(a, t_nn, wave);
+    cur ^= 1;
+  }
+}
+
 // Vertex rows with 8 .. 15 neighbours: SIXTEEN lanes per row, lane i = slot i of the fan (the
 // rows are scattered over the mesh -- ~13 % of the vertices of a Delaunay mesh -- so everything
 // goes by global ids).  A lane evaluates its slot's triangle, takes what the previous slot's
@@ -383,6 +696,115 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
       return fail(TFEM_ERR_INDEX_RANGE, "an array of %lld bytes does not fit the 32-bit offsets "
                   "of the P2 row kernel", (long long)e);
   const bool mass = beta != 0.0;
+  // row 0 (vertex DoF at p0) / row 3 (edge DoF (p0, p1)) of the constant maps, in T, sums in
+  // quadrature order like the reference's (integrand * dx).sum(-3)
+  auto fill_tables = [&](int kind, T (&oa)[6], T (&ob)[6], T (&od)[6], T (&om)[6]) {
+    const int row = kind == 0 ? 0 : 3;
+    for (int m = 0; m < 6; ++m) {
+      T ca = T(0), cb = T(0), cd = T(0), cm = T(0);
+      for (int q = 0; q < tables.nq; ++q) {
+        const T hw = T(tables.hw[q]);
+        const T r0 = T(tables.rgrad2[q][row][0]), r1 = T(tables.rgrad2[q][row][1]);
+        const T m0 = T(tables.rgrad2[q][m][0]), m1 = T(tables.rgrad2[q][m][1]);
+        ca = ca + hw * (r0 * m0);
+        cb = cb + hw * (r0 * m1 + r1 * m0);
+        cd = cd + hw * (r1 * m1);
+        cm = cm + hw * (T(tables.phi2[q][row]) * T(tables.phi2[q][m]));
+      }
+      oa[m] = T(alpha) * ca;
+      ob[m] = T(alpha) * cb;
+      od[m] = T(alpha) * cd;
+      om[m] = T(beta) * cm;
+    }
+  };
+  // TFEM_P2_PERSIST=1: ONE persistent, software-pipelined launch for both kinds of row
+  // (k_p2_rows_all).  Measured at S(707) = 999,698 elements (profiles/r03_p2_persistent.log): 55.5 us
+  // against 50.7 us for the two launches below -- both move their 273 MB at 5.0-5.4 TB/s, the rate of
+  // a mixed read / write stream on this part; what separates them from the 216 MB the roofline
+  // counts are the row records and the coordinate gathers of the edge tiles, not the launch
+  // structure.  The two launches stay the default.
+  bool persist = false;
+  if (const char *v = std::getenv("TFEM_P2_PERSIST")) persist = std::atoi(v) != 0;
+  if (persist) {
+    P2AllArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.coords = static_cast<const T *>(coords);
+    a.plan = plan;
+    a.vals = static_cast<T *>(vals);
+    a.coords_bytes = unsigned(extents[0]);
+    a.plan_bytes = unsigned(extents[1]);
+    a.vals_bytes = unsigned(extents[2]);
+    for (int kind = 0; kind < 2; ++kind) {
+      a.off_desc[kind] = unsigned(z[10 + 3 * kind]);
+      a.off_rows[kind] = unsigned(z[11 + 3 * kind]);
+      a.off_gid[kind] = unsigned(z[12 + 3 * kind]);
+      a.n_tiles[kind] = int(z[kind]);
+      fill_tables(kind, a.ca[kind], a.cb[kind], a.cd[kind], a.cm[kind]);
+    }
+    a.lds_vert = (int(std::max(z[4], z[5])) + 1) & ~1;
+    if (const char *v = std::getenv("TFEM_P2_NT")) a.nt_stores = std::atoi(v);
+    if (a.lds_vert > kP2LocalPerLane * kP2Block)
+      return fail(TFEM_ERR_INVALID_ARGUMENT, "P2 row plan exceeds the kernel's capacities");
+    const size_t lds = size_t(4 * a.lds_vert) * sizeof(T) + size_t(kP2Waves) * size_t(kP2StageHalf) * sizeof(T);
+    void *kernel = mass ? reinterpret_cast<void *>(k_p2_rows_all<T, true>) : reinterpret_cast<void *>(k_p2_rows_all<T, false>);
+    static std::mutex occ_mutex;
+    static struct { void *kernel; size_t lds; int per_cu; } occ[8];
+    static int occ_used = 0;
+    int per_cu = 0;
+    {
+      std::lock_guard<std::mutex> guard(occ_mutex);
+      for (int i = 0; i < occ_used; ++i)
+        if (occ[i].kernel == kernel && occ[i].lds == lds) per_cu = occ[i].per_cu;
+      if (per_cu == 0) {
+        if (lds > 64 * 1024) {
+          hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+          if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kP2Block, lds);
+        if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+        if (occ_used < 8) {
+          occ[occ_used].kernel = kernel;
+          occ[occ_used].lds = lds;
+          occ[occ_used++].per_cu = per_cu;
+        }
+      }
+    }
+    if (const char *v = std::getenv("TFEM_P2_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(v)));
+    int cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    static int cu_count = 0;
+    if (cu_count == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cu_count = prop.multiProcessorCount;
+    if (cu_count > 0) cus = cu_count;
+    const int64_t n_all = z[0] + z[1];
+    const int per = int((n_all + 31) / 32) * 4;
+    const int blocks = std::min(per * 8, (cus * per_cu / 8) * 8);
+    const dim3 grid{unsigned(blocks)}, block{unsigned(kP2Block)};
+    void *params[] = {&a};
+    hipError_t e = hipLaunchKernel(kernel, grid, block, params, lds, stream);
+    if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 row kernel launch: %s", hipGetErrorString(e));
+    if (z[18] > 0) {  // the vertex rows with 8 .. 15 neighbours
+      P2RowArgs<T> la;
+      std::memset(&la, 0, sizeof(la));
+      la.coords = a.coords;
+      la.plan = plan;
+      la.vals = a.vals;
+      for (int m = 0; m < 6; ++m) {
+        la.ca[m] = a.ca[0][m];
+        la.cb[m] = a.cb[0][m];
+        la.cd[m] = a.cd[0][m];
+        la.cm[m] = a.cm[0][m];
+      }
+      const dim3 lgrid{unsigned((16 * z[18] + kP2Block - 1) / kP2Block)};
+      if (mass)
+        hipLaunchKernelGGL((k_p2_long_rows<T, true>), lgrid, block, 0, stream, la, unsigned(z[17]), int(z[18]));
+      else
+        hipLaunchKernelGGL((k_p2_long_rows<T, false>), lgrid, block, 0, stream, la, unsigned(z[17]), int(z[18]));
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(TFEM_ERR_HIP, "P2 long-row kernel launch: %s", hipGetErrorString(e));
+    }
+    return TFEM_OK;
+  }
   for (int kind = 0; kind < 2; ++kind) {
     if (z[kind] == 0) continue;
     P2RowArgs<T> a;
@@ -400,25 +822,7 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
     a.xcd_ranges = 1;
     if (const char *v = std::getenv("TFEM_P2_XCD")) a.xcd_ranges = std::strcmp(v, "interleave") != 0;
     a.lds_vert = (int(z[4 + kind]) + 1) & ~1;
-    // row 0 (vertex DoF at p0) / row 3 (edge DoF (p0, p1)) of the constant maps, in T, sums in
-    // quadrature order like the reference's (integrand * dx).sum(-3)
-    const int row = kind == 0 ? 0 : 3;
-    for (int m = 0; m < 6; ++m) {
-      T ca = T(0), cb = T(0), cd = T(0), cm = T(0);
-      for (int q = 0; q < tables.nq; ++q) {
-        const T hw = T(tables.hw[q]);
-        const T r0 = T(tables.rgrad2[q][row][0]), r1 = T(tables.rgrad2[q][row][1]);
-        const T m0 = T(tables.rgrad2[q][m][0]), m1 = T(tables.rgrad2[q][m][1]);
-        ca = ca + hw * (r0 * m0);
-        cb = cb + hw * (r0 * m1 + r1 * m0);
-        cd = cd + hw * (r1 * m1);
-        cm = cm + hw * (T(tables.phi2[q][row]) * T(tables.phi2[q][m]));
-      }
-      a.ca[m] = T(alpha) * ca;
-      a.cb[m] = T(alpha) * cb;
-      a.cd[m] = T(alpha) * cd;
-      a.cm[m] = T(beta) * cm;
-    }
+    fill_tables(kind, a.ca, a.cb, a.cd, a.cm);
     const int max_len = kind == 0 ? kP2VertexRowMax : kP2EdgeRowMax;
     const size_t lds = size_t(2 * a.lds_vert) * sizeof(T) + size_t(kP2Waves) * size_t(64 * max_len + 2) * sizeof(T);
     void *kernel = kind == 0 ? (mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true>)

@@ -1239,3 +1239,29 @@ def test_assembly_launches_can_be_captured_in_a_hip_graph():
     torch.cuda.synchronize()
     assert scaled_error(out[1].cpu(), (2.0 * f.view(-1)).cpu()) <= 1e-15
     assert torch.equal(out[0], vals.view(-1))
+
+
+@pytest.mark.parametrize("mesh_kind", ["structured", "delaunay_morton"])
+@pytest.mark.parametrize("beta", [0.0, 0.75])
+def test_p2_persistent_launch_equals_the_two_launches(mesh_kind, beta, monkeypatch):
+    """TFEM_P2_PERSIST=1 (k_p2_rows_all: vertex and edge rows in one persistent, software-pipelined
+    launch; not the default, it is slower) writes the same operator as the two launches of
+    k_p2_rows, long rows included."""
+    from pytorch_fem_solver_amd import meshgen
+
+    if mesh_kind == "structured":
+        mesh_np = meshgen.unit_square(90, 0.25, 2)
+    else:
+        mesh_np = meshgen.delaunay_square(9000, 4)
+        mesh_np = meshgen.permute_mesh(mesh_np, vertex_order=meshgen.morton_order(mesh_np["vertices"]))
+    out = {}
+    for persist in ("0", "1"):
+        monkeypatch.setenv("TFEM_P2_PERSIST", persist)
+        basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(2, 4))
+        eng = basis._engine
+        assert eng.kernel_name() == "k_p2_rows"
+        vals = eng.bilinear(1.0, beta)
+        torch.cuda.synchronize()
+        out[persist] = vals.cpu().numpy().copy()
+    assert np.isfinite(out["1"]).all()
+    assert scaled_error(out["1"], out["0"]) <= 1e-14
