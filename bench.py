@@ -354,6 +354,7 @@ def delaunay_configs(n_points, order):
             "workload": f"Delaunay mesh of {nv} random points, {ne} elements, "
             f"{'Morton-renumbered vertices' if name == 'D_morton' else 'native scipy numbering'}, order {order}",
             "kernel": eng.kernel_name(),
+            "renumbered_by_the_engine": bool(eng.renumbered),
             "plan": None if rings is None else ("consecutive-vertex tiles" if rings["chunked"] else "Z-order tiles"),
             "setup_ms": setup_ms,
             "stiffness_only": {"kernel_ms": k_ms, "frac": algo_k / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

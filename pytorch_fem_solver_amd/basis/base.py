@@ -36,7 +36,9 @@ class _LinearFormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         basis = ctx.basis
-        conn = basis._engine._inputs()["conn_dof"].long()
+        # the caller's DoF ids (the engine may work in a renumbering of its own)
+        conn = basis._global_dofs4elements.to(grad_out.device).long()
+        conn = conn.reshape(-1, conn.shape[-1])
         dx = basis._dx.to(grad_out.device)
         lead = tuple(dx.shape[:-3])
         g = grad_out.reshape(-1)[conn].reshape(lead + (1, conn.shape[-1], 1))

@@ -311,6 +311,25 @@ class _LazyTriple:
         return 3
 
 
+def _morton_permutation(coords):
+    """Vertex ids along the Morton (Z-order) curve of their coordinates, on the tensor's own
+    device: 21 bits per axis, interleaved; ties keep the caller's order (stable sort)."""
+    xy = coords.detach().double()
+    lo = xy.min(dim=0).values
+    span = (xy.max(dim=0).values - lo).max().clamp_min(1e-300)
+    q = ((xy - lo) / span * float((1 << 21) - 1)).to(torch.int64).clamp_(0, (1 << 21) - 1)
+
+    def spread(v):  # abc -> 0a0b0c
+        v = (v | (v << 16)) & 0x0000FFFF0000FFFF
+        v = (v | (v << 8)) & 0x00FF00FF00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0F
+        v = (v | (v << 2)) & 0x3333333333333333
+        return (v | (v << 1)) & 0x5555555555555555
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1)
+    return torch.sort(code, stable=True).indices
+
+
 class AssemblyEngine:
     def __init__(self, coords, conn_geo, conn_dof, n_dofs, poly_order, quad_order, fracture=None):
         """coords (N_v,2) or (F,N_v,2); conn_geo (N_T,3) or (F,N_T,3) vertex ids (per mesh);
@@ -332,6 +351,22 @@ class AssemblyEngine:
         self.n_local = int(conn_dof.shape[-1])
         self.n_fractures = int(coords.shape[0]) if coords.dim() == 3 else 0
         self.coords_per_mesh = int(coords.shape[-2])
+        #: engine numbering -> caller's DoF (and back), or None: a P1 mesh whose vertex numbering has
+        #: no locality (a mesh generator's output order) is renumbered along the Morton curve HERE,
+        #: once -- every plan, kernel and array of the engine then lives in that numbering (the row
+        #: kernels stream coordinates and CSR values contiguously), and the engine translates at its
+        #: boundary: vectors go out / come in in the caller's numbering, operators carry `perm`
+        self._perm = self._inv = None
+        self._boundary_depth = 0  # > 0 inside a public method: nested calls stay in engine numbering
+        self.kernel = os.environ.get("TFEM_KERNEL", "auto")
+        if self._wants_renumbering(coords, conn_geo, conn_dof):
+            perm = _morton_permutation(coords)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=perm.device)
+            coords = coords[perm]
+            conn_geo = inv[conn_geo.long()].to(conn_geo.dtype)
+            conn_dof = conn_geo if conn_dof.shape == conn_geo.shape else inv[conn_dof.long()].to(conn_dof.dtype)
+            self._perm, self._inv = perm, inv
         self._host_coords = coords
         self._host_conn_geo = conn_geo
         self._host_conn_dof = conn_dof.reshape(-1, self.n_local)
@@ -352,7 +387,48 @@ class AssemblyEngine:
         self._edge_cells_checked = None  # (data_ptr, rows) of the last validated edge -> cells table
         #: "auto" (the best plan the mesh allows), "rings", "tiles", "rows" (P2 row kernels),
         #: "gather" (element blocks / vectors + gather, no plan) or "atomic" (one-pass scatter)
-        self.kernel = os.environ.get("TFEM_KERNEL", "auto")
+        #: (read at the top of the constructor)
+
+    # ------------------------------------------------------------------ renumbering
+    #: meshes below this many DoFs keep the caller's numbering (nothing to gain, and their CSR
+    #: arrays stay directly comparable); TFEM_RENUMBER=0 / 1 switches the renumbering off / forces it
+    RENUMBER_MIN_DOFS = int(os.environ.get("TFEM_RENUMBER_MIN", "50000"))
+
+    def _wants_renumbering(self, coords, conn_geo, conn_dof):
+        switch = os.environ.get("TFEM_RENUMBER", "")
+        if switch == "0" or self.kernel != "auto" or self.poly_order != 1 or coords.dim() != 2 or conn_geo.dim() != 2:
+            return False
+        if conn_dof.shape != conn_geo.shape or self.n_elems == 0:
+            return False
+        a, b = conn_geo.reshape(-1), conn_dof.reshape(-1)
+        if not (a.data_ptr() == b.data_ptr() or torch.equal(a.long(), b.to(a.device).long())):
+            return False
+        if switch == "1":
+            return True
+        if self.n_dofs < self.RENUMBER_MIN_DOFS:
+            return False
+        # locality of the numbering: the ids of two vertices of an element differ by about sqrt(N)
+        # in a structured or curve-ordered numbering, by about N / 3 in a random one
+        spread = (conn_geo[:, 0].long() - conn_geo[:, 1].long()).abs().double().median().item()
+        return spread > 32.0 * (self.n_dofs ** 0.5)
+
+    @property
+    def renumbered(self):
+        return self._perm is not None
+
+    def _dofs_out(self, vec):
+        """A per-DoF vector of the engine -> the caller's numbering."""
+        if self._perm is None or vec is None:
+            return vec
+        flat = vec.reshape(-1)
+        return flat.index_select(0, self._inv.to(flat.device)).reshape(vec.shape)
+
+    def _dofs_in(self, vec):
+        """A per-DoF vector of the caller -> the engine's numbering."""
+        if self._perm is None or vec is None:
+            return vec
+        flat = vec.reshape(-1)
+        return flat.index_select(0, self._perm.to(flat.device)).reshape(vec.shape)
 
     # ------------------------------------------------------------------ device state
     @property
@@ -618,6 +694,12 @@ class AssemblyEngine:
         )
 
     def set_priority_vertices(self, flags):
+        if self._perm is not None:
+            raise NotImplementedError("priority vertices (sharded runs) on an internally renumbered mesh: "
+                                      "the shards of a partition keep the numbering's locality")
+        return self._set_priority_vertices(flags)
+
+    def _set_priority_vertices(self, flags):
         """Multi-GPU: flag the vertices shared with other ranks BEFORE the first
         assembly; the ring plan then lists the tiles owning them first, and
         assemble_system(..., tiles="priority" / "rest") launches the two tile ranges, so the
@@ -783,7 +865,8 @@ class AssemblyEngine:
 
     def wrap_csr(self, vals):
         csr = self.csr_structure()
-        return CSRMatrix(csr[0], csr[1], vals, (self.n_dofs, self.n_dofs))
+        perm = None if self._perm is None else self._perm.to(vals.device)
+        return CSRMatrix(csr[0], csr[1], vals, (self.n_dofs, self.n_dofs), perm)
 
     def wrap_csr_home(self, vals):
         """The operator on the caller's device: the pattern is copied there once, the values
@@ -792,8 +875,10 @@ class AssemblyEngine:
             return self.wrap_csr(vals)
         if getattr(self, "_csr_home", None) is None:
             csr = self.csr_structure()
-            self._csr_home = (csr[0].to(self.home), csr[1].to(self.home))
-        return CSRMatrix(self._csr_home[0], self._csr_home[1], self._home(vals), (self.n_dofs, self.n_dofs))
+            self._csr_home = (csr[0].to(self.home), csr[1].to(self.home),
+                              None if self._perm is None else self._perm.to(self.home))
+        return CSRMatrix(self._csr_home[0], self._csr_home[1], self._home(vals), (self.n_dofs, self.n_dofs),
+                         self._csr_home[2])
 
     # ------------------------------------------------------------------ kernels
     def geometry(self):
@@ -1214,3 +1299,85 @@ class AssemblyEngine:
                 )
             )
         return out.reshape(tuple(full[:-3]) + (1,))
+
+
+# ---------------------------------------------------------------------------------------------
+# An internally renumbered engine (AssemblyEngine._perm) translates per-DoF vectors at its
+# boundary; everything inside -- plans, kernels, gather maps -- works in the engine's numbering.
+# ---------------------------------------------------------------------------------------------
+def _translate_vector_result(name):
+    inner = getattr(AssemblyEngine, name)
+
+    def method(self, *args, **kwargs):
+        if self._perm is None or self._boundary_depth:
+            return inner(self, *args, **kwargs)
+        given = kwargs.pop("out", None)
+        self._boundary_depth += 1
+        try:
+            result = inner(self, *args, **kwargs)
+        finally:
+            self._boundary_depth -= 1
+        result = self._dofs_out(result)
+        if given is not None:
+            self._output(given, result.numel(), "load vector").copy_(result.view(-1))
+            return given
+        return result
+
+    method.__name__, method.__doc__ = name, inner.__doc__
+    setattr(AssemblyEngine, name, method)
+
+
+def _translate_vector_argument(name, position, keyword):
+    inner = getattr(AssemblyEngine, name)
+
+    def method(self, *args, **kwargs):
+        if self._perm is not None and not self._boundary_depth:
+            if keyword in kwargs:
+                kwargs[keyword] = self._dofs_in(kwargs[keyword])
+            elif len(args) > position:
+                args = args[:position] + (self._dofs_in(args[position]),) + args[position + 1:]
+        return inner(self, *args, **kwargs)
+
+    method.__name__, method.__doc__ = name, inner.__doc__
+    setattr(AssemblyEngine, name, method)
+
+
+def _translate_system():
+    inner = AssemblyEngine.assemble_system
+
+    def assemble_system(self, alpha, beta, fq=None, out=None, source=None, tiles=None):
+        if self._perm is None or self._boundary_depth:
+            return inner(self, alpha, beta, fq, out, source, tiles)
+        if tiles is not None:
+            raise NotImplementedError("tile ranges (sharded runs) on an internally renumbered mesh")
+        self._boundary_depth += 1
+        try:
+            vals, f = inner(self, alpha, beta, fq, None if out is None else (out[0], None), source, None)
+        finally:
+            self._boundary_depth -= 1
+        f = self._dofs_out(f)
+        if out is not None and out[1] is not None:
+            self._output(out[1], f.numel(), "load vector").copy_(f.view(-1))
+            f = out[1]
+        return vals, f
+
+    assemble_system.__doc__ = inner.__doc__
+    AssemblyEngine.assemble_system = assemble_system
+
+    prepared = AssemblyEngine.prepared_system
+
+    def prepared_system(self, *args, **kwargs):
+        if self._perm is not None:
+            raise NotImplementedError("prepared launches write the engine's own numbering: not on an internally "
+                                      "renumbered mesh (TFEM_RENUMBER=0 keeps the caller's numbering)")
+        return prepared(self, *args, **kwargs)
+
+    prepared_system.__doc__ = prepared.__doc__
+    AssemblyEngine.prepared_system = prepared_system
+
+
+for _name in ("load", "load_source", "reduce_linear", "residual", "edge_interpolate_backward"):
+    _translate_vector_result(_name)
+_translate_vector_argument("edge_interpolate", 2, "u")
+_translate_vector_argument("residual_backward", 0, "cotangent")
+_translate_system()

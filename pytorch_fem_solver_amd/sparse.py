@@ -14,13 +14,45 @@ from . import _native
 
 class CSRMatrix:
     """``crow_indices`` int64 (N+1), ``col_indices`` int32 (nnz, ascending per row),
-    ``values`` (nnz); all on one device."""
+    ``values`` (nnz); all on one device.
 
-    def __init__(self, crow_indices, col_indices, values, shape):
+    ``perm`` (int64 (N,) or None): the operator is stored in a RENUMBERING of the caller's DoFs --
+    row / column k of the stored pattern is DoF ``perm[k]`` of the caller.  The assembly engine
+    renumbers a mesh whose vertex numbering has no locality along a space-filling curve once, at
+    set-up, so that the row kernels stream coordinates and values contiguously; every method below
+    takes and returns vectors in the CALLER's numbering, ``to_dense`` gives the caller's matrix, and
+    ``caller_numbering()`` the plain CSR arrays in the caller's numbering."""
+
+    def __init__(self, crow_indices, col_indices, values, shape, perm=None):
         self.crow_indices = crow_indices
         self.col_indices = col_indices
         self.values = values
         self.shape = tuple(shape)
+        self.perm = perm
+        self._inv = None
+
+    def _inverse(self):
+        if self._inv is None:
+            self._inv = torch.empty_like(self.perm)
+            self._inv[self.perm] = torch.arange(self.perm.numel(), device=self.perm.device)
+        return self._inv
+
+    def _stored(self):
+        """The same stored arrays without the renumbering attached (vectors in stored numbering)."""
+        return CSRMatrix(self.crow_indices, self.col_indices, self.values, self.shape)
+
+    def caller_numbering(self):
+        """Plain CSRMatrix (perm None) with rows, columns and values in the caller's numbering."""
+        if self.perm is None:
+            return self
+        n = self.shape[0]
+        counts = self.crow_indices[1:] - self.crow_indices[:-1]
+        rows = self.perm[torch.repeat_interleave(torch.arange(n, device=self.device), counts)]
+        cols = self.perm[self.col_indices.long()]
+        order = torch.argsort(rows * n + cols)
+        crow = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+        crow[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        return CSRMatrix(crow, cols[order].to(torch.int32), self.values[order], self.shape)
 
     @property
     def nnz(self):
@@ -36,16 +68,22 @@ class CSRMatrix:
 
     def to(self, device):
         return CSRMatrix(
-            self.crow_indices.to(device), self.col_indices.to(device), self.values.to(device), self.shape
+            self.crow_indices.to(device), self.col_indices.to(device), self.values.to(device), self.shape,
+            None if self.perm is None else self.perm.to(device),
         )
 
     def to_sparse_csr(self):
+        if self.perm is not None:
+            return self.caller_numbering().to_sparse_csr()
         return torch.sparse_csr_tensor(
             self.crow_indices, self.col_indices.to(torch.int64), self.values, size=self.shape
         )
 
     def to_dense(self):
         n = self.shape[0]
+        if self.perm is not None:
+            inv = self._inverse()
+            return self._stored().to_dense()[inv][:, inv]
         if self.values.is_cuda:
             lib = _native.load()
             dense = torch.empty(self.shape, dtype=self.dtype, device=self.device)
@@ -70,6 +108,9 @@ class CSRMatrix:
 
     def matvec(self, x):
         """A @ x for x of shape (N,) or (N, 1): libtfem_hip's CSR kernel on the GPU."""
+        if self.perm is not None:
+            flat = x.to(self.device, self.dtype).reshape(-1)
+            return self._stored().matvec(flat[self.perm])[self._inverse()].reshape(x.shape)
         if not self.values.is_cuda:
             return self.to_sparse_csr() @ x
         lib = _native.load()
@@ -89,6 +130,8 @@ class CSRMatrix:
 
     def diagonal(self):
         """Diagonal entries (0 where a row stores none)."""
+        if self.perm is not None:
+            return self._stored().diagonal()[self._inverse()]
         n = self.shape[0]
         counts = self.crow_indices[1:] - self.crow_indices[:-1]
         rows = torch.repeat_interleave(torch.arange(n, device=self.device), counts)
@@ -104,6 +147,12 @@ class CSRMatrix:
         formed).  Returns (x, iterations, relative residual).  Stands where the reference's
         dense `reduce` + `torch.linalg.solve` (abstract_basis.py:114-117,177-195) stops being
         possible."""
+        if self.perm is not None:  # solve in the stored numbering, vectors translated at the boundary
+            inv = self._inverse()
+            to_stored = lambda v: None if v is None else v.to(self.device, self.dtype).reshape(-1)[self.perm]  # noqa: E731
+            free_s = None if free is None else inv[free.to(self.device).reshape(-1)]
+            x, it, res = self._stored().solve_cg(to_stored(b), free_s, to_stored(x0), rtol, maxiter)
+            return x[inv].reshape(b.shape), it, res
         n = self.shape[0]
         shape = b.shape
         b = b.to(self.device, self.dtype).reshape(-1)
@@ -137,4 +186,5 @@ class CSRMatrix:
         return x.reshape(shape), it, res
 
     def __repr__(self):
-        return f"CSRMatrix(shape={self.shape}, nnz={self.nnz}, dtype={self.dtype}, device={self.device})"
+        extra = "" if self.perm is None else ", stored in a renumbering of the DoFs"
+        return f"CSRMatrix(shape={self.shape}, nnz={self.nnz}, dtype={self.dtype}, device={self.device}{extra})"

@@ -60,11 +60,18 @@ def _random_mesh(rng):
     return verts, np.ascontiguousarray(tris.astype(np.int32))
 
 
+def _caller_values(eng, vals):
+    """CSR values in the caller's numbering (an engine that renumbered its mesh stores them in its own)."""
+    return eng.wrap_csr(vals).caller_numbering().values if eng.renumbered else vals
+
+
 @pytest.mark.parametrize("seed", range(N_P1))
-def test_random_p1_meshes_every_kernel_mode(seed):
+def test_random_p1_meshes_every_kernel_mode(seed, monkeypatch):
     from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
 
     rng = np.random.default_rng(1000 + seed)
+    if seed % 4 == 3:  # every fourth mesh through the engine's own Morton renumbering, whatever its size
+        monkeypatch.setenv("TFEM_RENUMBER", "1")
     verts, tris = _random_mesh(rng)
     nv = verts.shape[0]
     order = int(rng.integers(1, 5))
@@ -95,8 +102,10 @@ def test_random_p1_meshes_every_kernel_mode(seed):
             continue
         tried.append(kernel)
         fq_t = torch.tensor(fq_np, dtype=dtype)
+        vals = _caller_values(eng, vals)
         assert np.abs(vals.cpu().double().numpy() - want).max() / scale <= tol, (seed, kernel, eng.kernel_name())
         vals2, f = eng.assemble_system(alpha, beta, fq_t)
+        vals2 = _caller_values(eng, vals2)
         assert np.abs(vals2.cpu().double().numpy() - want).max() / scale <= tol, (seed, kernel, "system")
         assert scaled_error(f.cpu().double().numpy().reshape(-1), want_f) <= tol, (seed, kernel, "load")
         assert scaled_error(eng.load(fq_t).cpu().double().numpy().reshape(-1), want_f) <= tol
@@ -139,10 +148,14 @@ def test_random_p2_meshes_every_kernel_mode(seed):
 
 
 @pytest.mark.parametrize("seed", range(16))
-def test_random_meshes_through_the_public_api(seed):
+def test_random_meshes_through_the_public_api(seed, monkeypatch):
     """The reference's own forms through Basis.integrate_* on random meshes (CPU- or
-    GPU-resident, dense or CSR result, recognised and generic callables) against the oracle."""
+    GPU-resident, dense or CSR result, recognised and generic callables) against the oracle;
+    every third mesh through the engine's internal renumbering."""
     import math
+
+    if seed % 3 == 2:
+        monkeypatch.setenv("TFEM_RENUMBER", "1")
 
     import pytorch_fem_solver_amd as tfm
     from pytorch_fem_solver_amd import meshgen

@@ -1265,3 +1265,79 @@ def test_p2_persistent_launch_equals_the_two_launches(mesh_kind, beta, monkeypat
         out[persist] = vals.cpu().numpy().copy()
     assert np.isfinite(out["1"]).all()
     assert scaled_error(out["1"], out["0"]) <= 1e-14
+
+
+def test_engine_renumbers_a_mesh_without_locality_and_translates_at_its_boundary(monkeypatch):
+    """A generator's vertex order (scipy Delaunay: no locality) at >= 50,000 DoFs: the engine
+    renumbers the mesh along the Morton curve once, takes the ring kernel with consecutive-vertex
+    tiles, and everything a caller sees is in the caller's numbering -- the operator (CSRMatrix with
+    the renumbering attached: caller_numbering(), matvec, solve), load vectors, the public fused call,
+    autograd through the generic linear form, the interior-edge interpolation and its adjoint --
+    against the oracle and against the same mesh assembled without the renumbering."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.delaunay_square(56000, 17)
+    mesh_np.pop("neighbors", None)
+    nv = mesh_np["vertices"].shape[0]
+    mesh = tf().MeshTri(triangulation=mesh_np)
+    basis = tf().Basis(mesh, tf().ElementTri(1, 3))
+    eng = basis._engine
+    assert eng.renumbered and eng.kernel_name() == "k_p1_rings" and eng.ring_plan()["chunked"]
+    monkeypatch.setenv("TFEM_RENUMBER", "0")
+    plain = tf().Basis(mesh, tf().ElementTri(1, 3))
+    assert not plain._engine.renumbered and plain._engine.kernel_name() == "k_p1_tiles_pipe"
+    monkeypatch.delenv("TFEM_RENUMBER")
+
+    rowptr, colind, slots = orc.csr_pattern(mesh_np["triangles"], nv)
+    local, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, "stiffness_mass")
+    want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    K = basis.integrate_bilinear_form(stiffness_mass, layout="csr")
+    assert K.perm is not None and sorted(K.perm.cpu().tolist()) == list(range(nv))
+    C = K.caller_numbering()
+    assert C.perm is None
+    assert np.array_equal(C.crow_indices.cpu().numpy(), rowptr) and np.array_equal(C.col_indices.cpu().numpy(), colind)
+    assert rowwise_error(C.values.cpu(), want, rowptr) <= TOL
+    fl, _ = orc.p1_assemble(mesh_np["vertices"], mesh_np["triangles"], 3, "load")
+    want_f = orc.assemble_linear(fl, mesh_np["triangles"], nv)
+    f = basis.integrate_linear_form(load)
+    assert scaled_error(f.cpu(), want_f) <= TOL
+    K2, f2 = basis.assemble_system(stiffness_mass, load, layout="csr")
+    assert torch.equal(K2.values, K.values) and scaled_error(f2.cpu(), want_f) <= TOL
+    # source VALUES (a tensor coefficient) and the generic reduce + scatter path
+    fq = rhs(*torch.split(basis.integration_points, 1, dim=-1))
+    assert scaled_error(basis.integrate_linear_form(lambda b: fq * b.v).cpu(), want_f) <= TOL
+    fw, fw_plain = basis.integrate_linear_form(weak_residual, grad_field), plain.integrate_linear_form(weak_residual, grad_field)
+    assert scaled_error(fw.cpu(), fw_plain.cpu()) <= TOL
+    Kc = basis.integrate_bilinear_form(lambda b: b.v @ b.v_grad[..., [0]].mT, layout="csr").caller_numbering()
+    Kc_plain = plain.integrate_bilinear_form(lambda b: b.v @ b.v_grad[..., [0]].mT, layout="csr")
+    assert scaled_error(Kc.values.cpu(), Kc_plain.values.cpu()) <= TOL  # non-symmetric: rows and columns both translated
+    # the operator applied and solved in the caller's numbering
+    x = torch.sin(torch.arange(nv, dtype=torch.float64) * 0.37).reshape(-1, 1)
+    K_plain = plain.integrate_bilinear_form(stiffness_mass, layout="csr")
+    assert scaled_error(K.matvec(x).cpu(), K_plain.matvec(x).cpu()) <= TOL
+    assert scaled_error(K.diagonal().cpu(), K_plain.diagonal().cpu()) <= TOL
+    u = basis.solve(K, basis.solution_tensor(), f, method="cg")
+    u_plain = plain.solve(K_plain, plain.solution_tensor(), f, method="cg")
+    assert scaled_error(u.cpu(), u_plain.cpu()) <= 1e-8
+    # autograd through the generic linear form (cotangent gathered by the CALLER's DoF ids)
+    for b in (basis, plain):
+        coefficient = torch.ones_like(fq, requires_grad=True)
+        out = b.integrate_linear_form(lambda bb, c=coefficient: (c * fq) * torch.cos(bb.v))
+        (out.reshape(-1) * x.reshape(-1)).sum().backward()
+        b._test_grad = coefficient.grad.clone()
+    assert scaled_error(basis._test_grad.cpu(), plain._test_grad.cpu()) <= TOL
+    # interior edges: a vertex field in, its adjoint out
+    edge_basis = tf().InteriorEdgesBasis(mesh, tf().ElementLine(1, 2))
+    got = {}
+    for name, b in (("renumbered", basis), ("plain", plain)):
+        nodal = x.clone().requires_grad_(True)
+        val, grad = b.interpolate(edge_basis, nodal)
+        ((val**2).sum() + grad.sum()).backward()
+        got[name] = (val.detach(), grad.detach(), nodal.grad.clone())
+    for a, b in zip(got["renumbered"], got["plain"]):
+        assert scaled_error(a.cpu(), b.cpu()) <= 1e-11
+    # sharded runs keep their shards' numbering: refused on a renumbered engine, loudly
+    with pytest.raises(NotImplementedError):
+        eng.set_priority_vertices(np.zeros(nv, dtype=bool))
+    with pytest.raises(NotImplementedError):
+        eng.prepared_system(1.0, 0.0, (torch.empty(colind.shape[0]), torch.empty(nv)), source=None, fq=fq.reshape(-1, 4))
