@@ -38,7 +38,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def parse():

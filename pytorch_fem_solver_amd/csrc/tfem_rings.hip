@@ -262,6 +262,17 @@ static int launch_rings(const RingLaunch &L) {
                           : load ? size_t(3 * a.lds_elem + 4) * sizeof(T) : 0);
   const bool chunk = z[13] != 0;
   a.flags = L.flags > 0 ? L.flags : 0;
+  // Store policy of the CSR values (TFEM_RINGS_STORES=nt | plain overrides).  Measured at S(2236)
+  // and S(3162) (profiles/r03_k_store_policy.log): the matrix-only launch from COLD caches (behind
+  // 512 MB of unrelated reads) takes 81 us with plain stores against 99 us with non-temporal ones
+  // (74 % against 60 % of the roofline; 68 % against 59 % at 2e7 elements), behind unrelated writes
+  // both take 112-113 us; only launches of the SAME mesh in a row, whose read set then survives in
+  // the memory-side cache, prefer non-temporal stores (81-93 us against 100).  The launches that
+  // also form a load vector are bound by vector issue and run 3-20 % faster with non-temporal
+  // stores.  So: plain for the matrix alone, non-temporal with a load vector.
+  bool plain_stores = !load;
+  if (const char *v = std::getenv("TFEM_RINGS_STORES")) plain_stores = std::strcmp(v, "plain") == 0;
+  if (plain_stores) a.flags |= 1024;
   a.stamps = L.stamps;
   // programs that never hold more than two values: three elements per pass of the interpreter
   bool wide = src && src_depth(L.source) <= 2;

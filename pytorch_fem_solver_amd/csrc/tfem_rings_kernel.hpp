@@ -53,7 +53,8 @@ struct RingArgs {
   // off_hin: per owned row the local id its vertex has in the previous tile of the block (uint16)
   unsigned off_chain, off_hin;
   int chain_len, u_first;
-  int flags;      // ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
+  int flags;      // 1024: plain instead of non-temporal value stores (every build: the launch's store
+                  // policy).  Ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
                   // source-value loads, 64 no element-id loads, 128 no g staging, 256 stamps
   unsigned long long *stamps;  // ablation build, flag 256: 8 cycle sums per wave
@@ -294,7 +295,7 @@ __device__ __forceinline__ void ring_store_run1(const T *stage, int total, int d
     } else if (128 * (u + 1) <= total || s0 + 1 < total) {  // first test is wave-uniform
       if constexpr (sizeof(T) == 8) {
         const ru32x2 x = __builtin_bit_cast(ru32x2, v0), y = __builtin_bit_cast(ru32x2, v1);
-        if (DBG && (flags & 1024))  // ablation: plain (temporal) stores
+        if (flags & 1024)  // plain (temporal) stores: the launch's store policy (RingArgs::flags)
           __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, 0);
         else
           __builtin_amdgcn_raw_buffer_store_b128(ru32x4{x.x, x.y, y.x, y.y}, r_vals, byte, 0, kStreamNT);

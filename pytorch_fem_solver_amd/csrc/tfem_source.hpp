@@ -70,6 +70,22 @@ __device__ __forceinline__ double src_sin_poly(double r) {
   return __builtin_fma(r * r2, p, r);
 }
 
+// c * (r + r^3 P(r^2)) with the factor folded in: (c r) + (c r) r^2 P -- one multiplication instead
+// of one for r^3 and one for the factor behind the function
+__device__ __forceinline__ double src_sin_poly_scaled(double r, double c) {
+  const double r2 = r * r;
+  double p = 2.73144475909634011e-15;
+  p = __builtin_fma(p, r2, -7.64397029616579265e-13);
+  p = __builtin_fma(p, r2, 1.60589773124442683e-10);
+  p = __builtin_fma(p, r2, -2.50521076169958777e-08);
+  p = __builtin_fma(p, r2, 2.75573192191632300e-06);
+  p = __builtin_fma(p, r2, -1.98412698412549741e-04);
+  p = __builtin_fma(p, r2, 8.33333333333331587e-03);
+  p = __builtin_fma(p, r2, -1.66666666666666657e-01);
+  const double cr = c * r;
+  return __builtin_fma(cr * r2, p, cr);
+}
+
 constexpr double kSrcPiHi = 3.141592653589793116e+00, kSrcPiLo = 1.224646799147353207e-16;
 constexpr double kSrcInvPi = 0.318309886183790671537767526745;
 constexpr double kSrcTrigFastMax = 1.0e9;
@@ -95,6 +111,22 @@ __device__ __forceinline__ double src_sin_fast(double x) {
   double r = __builtin_fma(-k, kSrcPiHi, x);
   r = __builtin_fma(-k, kSrcPiLo, r);
   return src_flip_sign(src_sin_poly(r), src_low_word(kd));
+}
+
+__device__ __forceinline__ double src_sin_fast_scaled(double x, double c) {
+  const double kd = __builtin_fma(x, kSrcInvPi, kSrcRoundMagic);
+  const double k = kd - kSrcRoundMagic;
+  double r = __builtin_fma(-k, kSrcPiHi, x);
+  r = __builtin_fma(-k, kSrcPiLo, r);
+  return src_flip_sign(src_sin_poly_scaled(r, c), src_low_word(kd));
+}
+
+__device__ __forceinline__ double src_cos_fast_scaled(double x, double c) {
+  const double kd = __builtin_fma(x, kSrcInvPi, -0.5) + kSrcRoundMagic;
+  const double kh = (kd - kSrcRoundMagic) + 0.5;
+  double r = __builtin_fma(-kh, kSrcPiHi, x);
+  r = __builtin_fma(-kh, kSrcPiLo, r);
+  return src_flip_sign(src_sin_poly_scaled(r, c), ~src_low_word(kd));
 }
 
 __device__ __forceinline__ double src_cos_fast(double x) {
@@ -157,6 +189,41 @@ __device__ __forceinline__ void src_cos(T (&v)[QL]) {
 #pragma unroll
     for (int q = 0; q < QL; ++q) v[q] = cosf(v[q]);
   }
+}
+
+// top = c * sin(top) / c * cos(top): the factor goes into the polynomial's last steps on the fast path
+template <typename T, int QL>
+__device__ __forceinline__ void src_sin_scaled(T (&v)[QL], T c) {
+  if constexpr (sizeof(T) == 8) {
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) big = big || !(__builtin_fabs(v[q]) < kSrcTrigFastMax);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) v[q] = src_sin_fast_scaled(v[q], c);
+      return;
+    }
+  }
+  src_sin<T, QL>(v);
+#pragma unroll
+  for (int q = 0; q < QL; ++q) v[q] = c * v[q];
+}
+
+template <typename T, int QL>
+__device__ __forceinline__ void src_cos_scaled(T (&v)[QL], T c) {
+  if constexpr (sizeof(T) == 8) {
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < QL; ++q) big = big || !(__builtin_fabs(v[q]) < kSrcTrigFastMax);
+    if (__builtin_amdgcn_ballot_w64(big) == 0) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) v[q] = src_cos_fast_scaled(v[q], c);
+      return;
+    }
+  }
+  src_cos<T, QL>(v);
+#pragma unroll
+  for (int q = 0; q < QL; ++q) v[q] = c * v[q];
 }
 
 template <typename T>
@@ -273,8 +340,8 @@ __device__ __forceinline__ void src_run(const SrcLanes<T> &prog, const T (&x)[QL
         break;
       }
       // the functions: top = c * fn(top)
-      case TFEM_SRC_SIN: src_sin<T, QL>(s0); TFEM_SRC_SET(c * t) break;
-      case TFEM_SRC_COS: src_cos<T, QL>(s0); TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_SIN: src_sin_scaled<T, QL>(s0, c); break;
+      case TFEM_SRC_COS: src_cos_scaled<T, QL>(s0, c); break;
       case TFEM_SRC_EXP:
         if constexpr (sizeof(T) == 8) { TFEM_SRC_SET(c * exp(t)) } else { TFEM_SRC_SET(c * expf(t)) }
         break;
@@ -353,7 +420,8 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
 #pragma unroll
         for (int e = 0; e < NE; ++e)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) vert[e][k] = xyc[2 * ((code[e] >> (10 * k)) & 0x3FFu) + comp];
+          for (int k = 0; k < 3; ++k)  // one bit-field extract + one shift-add per vertex
+            vert[e][k] = xyc[2 * __builtin_amdgcn_ubfe(code[e], 10 * k, 10) + comp];
 #pragma unroll
         for (int e = 0; e < NE; ++e)
 #pragma unroll
@@ -391,8 +459,8 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
       case TFEM_SRC_SIN: TFEM_SRC_SET(c * t) break;
       case TFEM_SRC_COS: TFEM_SRC_SET(c * t) break;
 #else
-      case TFEM_SRC_SIN: src_sin<T, N>(s0); TFEM_SRC_SET(c * t) break;
-      case TFEM_SRC_COS: src_cos<T, N>(s0); TFEM_SRC_SET(c * t) break;
+      case TFEM_SRC_SIN: src_sin_scaled<T, N>(s0, c); break;
+      case TFEM_SRC_COS: src_cos_scaled<T, N>(s0, c); break;
 #endif
       case TFEM_SRC_EXP:
         if constexpr (sizeof(T) == 8) { TFEM_SRC_WIDE_APPLY(s0, exp) } else { TFEM_SRC_WIDE_APPLY(s0, expf) }

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Developer tool (GPU box): rocprofv3 kernel trace and PMC passes of the bench command.
-#   bash tools/profile_bench.sh            (writes under gpurun_out/prof_r02/)
+#   bash tools/profile_bench.sh            (writes under gpurun_out/prof_r03/)
 # Counters go in their own passes, with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
 set -e
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_r02
+OUT=gpurun_out/prof_r03
 mkdir -p $OUT
 CMD="python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $CMD > $OUT/bench_under_rocprof.log 2>&1

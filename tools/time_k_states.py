@@ -22,11 +22,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2236
 mesh_np = meshgen.unit_square(n, 0.25, 0)
 ne, nv = mesh_np["triangles"].shape[0], mesh_np["vertices"].shape[0]
 scrub = torch.empty(64 * 1024 * 1024)  # 512 MB
-for label, dbg in (("product kernel (non-temporal stores)", None), ("ablation build, non-temporal stores", "2048"),
-                   ("ablation build, plain stores", "1024")):
-    os.environ.pop("TFEM_RINGS_DEBUG", None)
-    if dbg:
-        os.environ["TFEM_RINGS_DEBUG"] = dbg
+for label, policy in (("non-temporal value stores", "nt"), ("plain value stores", "plain")):
+    os.environ["TFEM_RINGS_STORES"] = policy
     basis = tf.Basis(tf.MeshTri(mesh_np), tf.ElementTri(1, 3))
     eng = basis._engine
     nnz = int(eng.csr_structure()[1].shape[0])
@@ -54,8 +51,17 @@ for label, dbg in (("product kernel (non-temporal stores)", None), ("ablation bu
         return a.elapsed_time(b) * 1e3
 
     print(label)
-    for state, pause in (("back to back", 0), ("reads", 0), ("writes", 0), ("writes", 200), ("writes", 2000)):
+    # launches in a row, no host synchronisation in between (what bench.py calls back to back)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50):
+        eng.bilinear(1.0, 0.0, out=vals)
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) * 1e3 / 50
+    print(f"    50 launches in a row                   : {t:7.1f} us = {alg / t / 8e6 * 100:5.1f} % of 8 TB/s", flush=True)
+    for state, pause in (("back to back", 0), ("reads", 0), ("writes", 0), ("writes", 2000)):
         one(state, pause)
         t = float(np.median([one(state, pause) for _ in range(15)]))
-        print(f"    behind {state:13s} pause {pause:5d} us: {t:7.1f} us = {alg / t / 8e6 * 100:5.1f} % of 8 TB/s", flush=True)
+        print(f"    single launch behind {state:13s} pause {pause:5d} us: {t:7.1f} us = {alg / t / 8e6 * 100:5.1f} % of 8 TB/s", flush=True)
     del basis, eng, vals
