@@ -367,6 +367,23 @@ class AssemblyEngine:
             conn_geo = inv[conn_geo.long()].to(conn_geo.dtype)
             conn_dof = conn_geo if conn_dof.shape == conn_geo.shape else inv[conn_dof.long()].to(conn_dof.dtype)
             self._perm, self._inv = perm, inv
+        elif self._wants_edge_renumbering(coords, conn_geo, conn_dof):
+            # P2 ("vertices, then edges"): the edge DoFs in the order of the mesh's edge list --
+            # a generator's strips -- are renumbered along the Morton curve of the edge midpoints:
+            # 256 consecutive edge rows then touch ~150 vertices instead of ~720, and the edge
+            # tiles of the row plan gather a fifth of the coordinates
+            n_v, n_e = self.coords_per_mesh, self.n_dofs - self.coords_per_mesh
+            tri, edge = conn_geo.long(), conn_dof.long()[:, 3:] - n_v
+            mid = torch.zeros((n_e, 2), dtype=coords.dtype, device=coords.device)
+            for j in range(3):  # local edge j = (v_j, v_{j+1}) (element_tri.py:50-52)
+                mid[edge[:, j]] = 0.5 * (coords[tri[:, j]] + coords[tri[:, (j + 1) % 3]])
+            edge_perm = _morton_permutation(mid)
+            edge_inv = torch.empty_like(edge_perm)
+            edge_inv[edge_perm] = torch.arange(n_e, device=edge_perm.device)
+            conn_dof = torch.cat([conn_dof[:, :3].long(), n_v + edge_inv[edge]], dim=1).to(conn_dof.dtype)
+            ids = torch.arange(n_v, device=edge_perm.device)
+            self._perm = torch.cat([ids, n_v + edge_perm])
+            self._inv = torch.cat([ids, n_v + edge_inv])
         self._host_coords = coords
         self._host_conn_geo = conn_geo
         self._host_conn_dof = conn_dof.reshape(-1, self.n_local)
@@ -411,6 +428,18 @@ class AssemblyEngine:
         # in a structured or curve-ordered numbering, by about N / 3 in a random one
         spread = (conn_geo[:, 0].long() - conn_geo[:, 1].long()).abs().double().median().item()
         return spread > 32.0 * (self.n_dofs ** 0.5)
+
+    def _wants_edge_renumbering(self, coords, conn_geo, conn_dof):
+        switch = os.environ.get("TFEM_RENUMBER", "")
+        if switch == "0" or self.kernel != "auto" or self.poly_order != 2 or coords.dim() != 2 or conn_geo.dim() != 2:
+            return False
+        if conn_dof.dim() != 2 or conn_dof.shape[-1] != 6 or self.n_elems == 0 or self.n_dofs <= self.coords_per_mesh:
+            return False
+        if switch != "1" and self.n_dofs < self.RENUMBER_MIN_DOFS:
+            return False
+        # the layout the row plan needs: vertex DoF id = vertex id, then the edges
+        head = conn_dof[:, :3].to(conn_geo.device)
+        return bool(torch.equal(head.long(), conn_geo.long()) and int(conn_dof[:, 3:].min()) >= self.coords_per_mesh)
 
     @property
     def renumbered(self):

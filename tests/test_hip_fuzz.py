@@ -113,11 +113,13 @@ def test_random_p1_meshes_every_kernel_mode(seed, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(N_P2))
-def test_random_p2_meshes_every_kernel_mode(seed):
+def test_random_p2_meshes_every_kernel_mode(seed, monkeypatch):
     from pytorch_fem_solver_amd import dofs, meshgen
     from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
 
     rng = np.random.default_rng(2000 + seed)
+    if seed % 3 == 2:  # the engine's own order of the edge DoFs (Morton order of the midpoints)
+        monkeypatch.setenv("TFEM_RENUMBER", "1")
     if seed % 2 == 0:
         mesh = meshgen.unit_square(int(rng.integers(2, 50)), float(rng.uniform(0.0, 0.3)), seed)
     else:
@@ -139,12 +141,22 @@ def test_random_p2_meshes_every_kernel_mode(seed):
     local = orc.integrate_local(integrand, geo["dx"])
     _, colind, slots = orc.csr_pattern(conn6, xy.shape[0])
     want = orc.assemble_csr_values(local, slots, colind.shape[0])
+    loads = {}
     for kernel in ("auto", "gather", "atomic"):
         eng = AssemblyEngine(torch.tensor(mesh["vertices"]), torch.tensor(tris), torch.tensor(conn6),
                              xy.shape[0], 2, order)
         eng.kernel = kernel
-        vals = eng.bilinear(alpha, beta)
+        assert eng.renumbered == (seed % 3 == 2)
+        vals = _caller_values(eng, eng.bilinear(alpha, beta))
         assert scaled_error(vals.cpu().numpy(), want) <= 1e-12, (seed, kernel, eng.kernel_name())
+        fq = torch.tensor(np.cos(np.arange(tris.shape[0] * eng.n_quad)).reshape(tris.shape[0], -1))
+        if kernel == "auto":  # per-DoF vectors leave the engine in the caller's numbering
+            loads[eng.renumbered] = eng.load(fq).cpu().numpy()
+    if True in loads:  # the same vector as the engine gives without its renumbering
+        monkeypatch.setenv("TFEM_RENUMBER", "0")
+        plain = AssemblyEngine(torch.tensor(mesh["vertices"]), torch.tensor(tris), torch.tensor(conn6), xy.shape[0], 2, order)
+        fq = torch.tensor(np.cos(np.arange(tris.shape[0] * plain.n_quad)).reshape(tris.shape[0], -1))
+        assert scaled_error(loads[True], plain.load(fq).cpu().numpy()) <= 1e-12
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -781,8 +781,13 @@ def test_p2_config3_properties_1e6():
     geo = orc.geometry(cells, 2, 2)
     local = orc.integrate_local(orc.integrand_stiffness(geo), geo["dx"])
     conn6 = basis._global_dofs4elements.cpu().numpy()[sample]
-    dense_rows = K.to_sparse_csr()
-    crow, col, val = (K.crow_indices.cpu().numpy(), K.col_indices.cpu().numpy(), K.values.cpu().numpy())
+    # the engine keeps P2 edge DoFs in an order of its own (Morton order of the edge midpoints): the
+    # arrays in the CALLER's numbering
+    assert basis._engine.renumbered and K.perm is not None
+    plain = K.caller_numbering()
+    crow, col, val = (plain.crow_indices.cpu().numpy(), plain.col_indices.cpu().numpy(), plain.values.cpu().numpy())
+    o_rowptr, o_colind, _ = orc.csr_pattern(basis._global_dofs4elements.cpu().numpy(), n)
+    assert np.array_equal(crow, o_rowptr) and np.array_equal(col, o_colind)  # the oracle's pattern
     for e in range(sample.shape[0]):
         # vertex-vertex entries get contributions from other elements too; the entry between
         # the element's two "own" edge DoFs of edges 0 and 1 belongs to this element alone
