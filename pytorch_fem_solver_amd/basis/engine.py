@@ -248,6 +248,9 @@ def unpack_ring_plan(blob, layout):
         "chain_len": z[25],
         "hand_in": np.frombuffer(blob, dtype=np.uint16, count=z[1], offset=z[26]),
         "max_n_tv": z[27],
+        # z[28] >= 0: balanced blocks (that many of chain_len positions, then z[29] blocks of the rest)
+        "chain_big": z[28],
+        "chain_wgs": z[29],
     }
 
 

@@ -236,10 +236,19 @@ static int launch_rings(const RingLaunch &L) {
   // a tile's index only addresses its descriptor; the launches of a source program walk positions
   // [t_first, t_first + t_count) of the chain order instead (the same tiles for the ranges the
   // plan knows: the tiles owning flagged vertices come first in both orders)
-  if (src)
+  a.chain_big = -1;
+  a.chain_wgs = 1;
+  if (src) {
     a.u_first = int(t_first);
-  else
+    if (z[28] >= 0 && (t_first != 0 || t_count != z[0]))
+      return fail(TFEM_ERR_UNSUPPORTED, "tile ranges need a plan built with flagged vertices (its blocks break between the ranges)");
+    if (z[28] >= 0) {  // balanced blocks (plans without flagged vertices): the whole plan in one launch
+      a.chain_big = int(z[28]);
+      a.chain_wgs = int(z[29]);
+    }
+  } else {
     a.off_desc += 80u * unsigned(t_first);
+  }
   a.lds_vert = (int(z[3]) + 1) & ~1;
   // W = sum_q w_q/2 and M_ij = sum_q (w_q/2) l_i l_j, formed in T in quadrature order.  The
   // rules of element_tri.py:77-130 are symmetric, so M has one diagonal and one off-diagonal
@@ -316,6 +325,7 @@ static int launch_rings(const RingLaunch &L) {
   if (src) {  // blocks of the chain order, dealt to the XCDs round-robin: workgroups per XCD that get one
     const int64_t first_block = t_first / a.chain_len, last_block = (t_first + t_count - 1) / a.chain_len;
     per = int((last_block - first_block + 1 + 7) / 8);
+    if (a.chain_big >= 0) per = (a.chain_big + a.chain_wgs + 7) / 8;
   }
   if (L.blocks_per_cu > 0 && L.blocks_per_cu < per_cu) per_cu = L.blocks_per_cu;
   // TFEM_RINGS_RESERVE_CUS: CUs per XCD this launch leaves free (a sharded step: the kernels of
@@ -331,7 +341,7 @@ static int launch_rings(const RingLaunch &L) {
   static int n_launch = 0;
   const bool stamp_now = src && kmat && ++n_launch == 300;
   if (stamp_now) {
-    if (!dev_stamps) (void)hipMalloc(&dev_stamps, sizeof(unsigned long long) * 10 * kRingWaves * 8192);
+    if (!dev_stamps) (void)hipMalloc(&dev_stamps, sizeof(unsigned long long) * 12 * kRingWaves * 8192);
     a.stamps = dev_stamps;
   }
 #endif
@@ -341,16 +351,26 @@ static int launch_rings(const RingLaunch &L) {
 #ifdef TFEM_SRC_TIMING
   if (stamp_now) {
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(size_t(10) * kRingWaves * size_t(blocks));
+    std::vector<unsigned long long> h(size_t(12) * kRingWaves * size_t(blocks));
     (void)hipMemcpy(h.data(), dev_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double sum[10] = {0};
-    for (size_t w = 0; w < size_t(kRingWaves) * size_t(blocks); ++w)
-      for (int i = 0; i < 10; ++i) sum[i] += double(h[10 * w + size_t(i)]);
+    double clk = 0, real = 0, real_max = 0, real_min = 1e300, tiles_max = 0;
+    for (size_t w = 0; w < size_t(kRingWaves) * size_t(blocks); ++w) {
+      for (int i = 0; i < 10; ++i) sum[i] += double(h[12 * w + size_t(i)]);
+      clk += double(h[12 * w + 10]);
+      real += double(h[12 * w + 11]);
+      real_max = std::max(real_max, double(h[12 * w + 11]));
+      real_min = std::min(real_min, double(h[12 * w + 11]));
+      tiles_max = std::max(tiles_max, double(h[12 * w + 7]));
+    }
     const char *names[10] = {"A loads", "B rows", "stage", "vmcnt", "park", "stores", "barrier E", "tiles", "G", "barrier G"};
-    std::fprintf(stderr, "[stamps] %d workgroups, cycles per tile and wave (s_memtime, 100 MHz units x ?):", blocks);
+    std::fprintf(stderr, "[stamps] %d workgroups, shader cycles per tile and wave (s_memtime):", blocks);
     for (int i = 0; i < 10; ++i)
       if (i != 7) std::fprintf(stderr, "  %s %.0f", names[i], sum[i] / sum[7]);
-    std::fprintf(stderr, "  tiles/wave %.1f\n", sum[7] / (double(kRingWaves) * blocks));
+    std::fprintf(stderr, "  tiles/wave %.1f  |  in-kernel clock %.3f GHz (shader cycles / 100 MHz ticks over the waves' tile loops), loop %.1f us\n",
+                 sum[7] / (double(kRingWaves) * blocks), clk / real * 0.1, real / (double(kRingWaves) * blocks) * 0.01);
+    std::fprintf(stderr, "[stamps] loop of the shortest / longest wave %.1f / %.1f us, most tiles of a wave %.0f\n",
+                 real_min * 0.01, real_max * 0.01, tiles_max);
   }
 #endif
   if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours

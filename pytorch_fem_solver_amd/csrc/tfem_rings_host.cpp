@@ -93,6 +93,12 @@ struct RingPlan {
   std::vector<int32_t> chain_order;  // position in the chain order -> tile
   std::vector<uint16_t> hand_in;     // parallel to rowstart
   int32_t chain_len = 1;
+  // chain_big >= 0: BALANCED blocks -- chain_big blocks of chain_len positions (every one of the
+  // chain_wgs resident workgroups of a launch gets the same number of them), then the remaining
+  // positions in chain_wgs blocks of equal length (+-1): a workgroup that takes blocks w, w + chain_wgs,
+  // w + 2 chain_wgs ... gets its equal share of the tiles.  chain_big < 0: blocks of chain_len
+  // positions throughout (plans with flagged vertices: the two launches of a sharded step).
+  int32_t chain_big = -1, chain_wgs = 1024;
   int32_t max_n_tv = 0;              // most elements a tile evaluates itself
 };
 
@@ -568,13 +574,28 @@ int emit_plan(const I *conn, const int64_t *adj_ptr, const int32_t *adj, const i
 // Blocks of the chain order one workgroup takes in a row.  Measured at S(2236) = 20,147 tiles on
 // 1024 resident workgroups (profiles/r03_chain_sweep.log): the fused K + f launch of sin * sin takes
 // 190 us with blocks of 1, 184 with 4, 172 with 8 and 16 (the doubly evaluated elements drop from
-// 27 % to 9 / 6 / 5 %), 239 with 32 (too few blocks per workgroup).  Blocks of up to 8, as long as
-// every workgroup still gets two of them.
+// 27 % to 9 / 6 / 5 %), 239 with 32 (too few blocks per workgroup).  Blocks of 8.
 int pick_chain_len(int64_t n_tiles) {
   if (const char *v = std::getenv("TFEM_RING_CHAIN")) return std::max(1, std::min(std::atoi(v), 64));
-  int64_t wgs = 1024;  // resident workgroups of the launch: 4 per CU of an MI355X
-  if (const char *v = std::getenv("TFEM_RING_WGS")) wgs = std::max(1, std::atoi(v));
-  return int(std::max<int64_t>(1, std::min<int64_t>(8, n_tiles / (2 * wgs))));
+  (void)n_tiles;
+  return 8;
+}
+
+// first position of every block: the plan's rule, which the kernel restates (tfem_rings_kernel.hpp)
+std::vector<uint8_t> chain_block_starts(int64_t n_tiles, int len, int64_t n_big, int64_t wgs, int64_t n_priority) {
+  std::vector<uint8_t> starts(size_t(n_tiles), 0);
+  if (n_big < 0) {
+    for (int64_t u = 0; u < n_tiles; u += len) starts[size_t(u)] = 1;
+    if (n_priority > 0 && n_priority < n_tiles) starts[size_t(n_priority)] = 1;  // two launches: no hand-over between them
+    return starts;
+  }
+  for (int64_t b = 0; b < n_big; ++b) starts[size_t(b * len)] = 1;
+  const int64_t rest = n_tiles - n_big * len, q = rest / wgs, r = rest % wgs;
+  for (int64_t w = 0; w < wgs; ++w) {
+    const int64_t start = n_big * len + w * q + std::min(w, r), count = q + (w < r ? 1 : 0);
+    if (count > 0) starts[size_t(start)] = 1;
+  }
+  return starts;
 }
 
 // Chain order, per-tile tables of the elements a tile evaluates itself, carry maps (RingPlan).
@@ -589,8 +610,19 @@ void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
   std::sort(plan.chain_order.begin() + plan.n_priority, plan.chain_order.end(), by_curve);
   const int len = pick_chain_len(n_tiles);
   plan.chain_len = len;
+  plan.chain_wgs = 1024;  // resident workgroups of a source-program launch: 4 per CU of an MI355X
+  if (const char *v = std::getenv("TFEM_RING_WGS")) plan.chain_wgs = std::max(8, std::atoi(v));
+  plan.chain_big = plan.n_priority > 0 ? -1 : int32_t((n_tiles / (int64_t(plan.chain_wgs) * len)) * plan.chain_wgs);
+  if (const char *v = std::getenv("TFEM_RING_BALANCED"))
+    if (std::atoi(v) == 0) plan.chain_big = -1;
+  const std::vector<uint8_t> starts = chain_block_starts(n_tiles, len, plan.chain_big, plan.chain_wgs, plan.n_priority);
   plan.hand_in.assign(plan.rowstart.size(), uint16_t(0xFFFF));
-  const int64_t n_blocks = (n_tiles + len - 1) / len;
+  // the blocks as ranges of positions
+  std::vector<int64_t> block_first;
+  for (int64_t u = 0; u < n_tiles; ++u)
+    if (starts[size_t(u)]) block_first.push_back(u);
+  block_first.push_back(n_tiles);
+  const int64_t n_blocks = int64_t(block_first.size()) - 1;
   std::vector<std::vector<uint32_t>> kept(static_cast<size_t>(n_tiles));
   int32_t *desc = plan.desc.data();
   auto elem_id = [&](const int32_t *d, int32_t j) {  // j-th element of the tile's ascending list
@@ -605,9 +637,7 @@ void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
     TileMap prev(16384), cur(16384), prev_local(2048);
     for (int64_t b = b0; b < b1; ++b) {
       bool have_prev = false;
-      for (int64_t u = b * len; u < std::min<int64_t>((b + 1) * len, n_tiles); ++u) {
-        // positions n_priority - 1 and n_priority belong to different launches: no hand-over
-        if (u == plan.n_priority) have_prev = false;
+      for (int64_t u = block_first[size_t(b)]; u < block_first[size_t(b) + 1]; ++u) {
         const int32_t t = plan.chain_order[size_t(u)];
         const int32_t *d = desc + size_t(t) * kRingDescStride;
         const int32_t n_elem = d[17];
@@ -617,7 +647,7 @@ void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
         cur.clear();
         for (int32_t j = 0; j < n_elem; ++j) {
           const int32_t e = elem_id(d, j);
-          if (have_prev && prev.has(e)) continue;  // the tile before evaluates it and hands the shares over
+          if (have_prev && prev.has(e)) continue;  // the tile before evaluates it and hands the sums over
           cur.put(e, 0);
           mine.push_back(codes[j]);
         }
@@ -630,9 +660,8 @@ void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
             if (prev_local.has(g)) plan.hand_in[size_t(d[2]) + size_t(r)] = uint16_t(prev_local.get(g));
           }
         }
-        const bool has_next = u + 1 < std::min<int64_t>((b + 1) * len, n_tiles) && u + 1 != plan.n_priority;
         std::swap(prev, cur);
-        have_prev = has_next;
+        have_prev = true;
       }
     }
   }, 16);
@@ -754,6 +783,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.chain_order.clear();
     plan.hand_in.clear();
     plan.chain_len = 1;
+    plan.chain_big = -1;
     plan.max_n_tv = 0;
   };
   std::vector<int32_t> vert_stamp(size_t(n_verts), -1);
@@ -979,6 +1009,8 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[14] = p.max_n_halo;
   layout[25] = p.chain_len;
   layout[27] = p.max_n_tv;
+  layout[28] = p.chain_big;
+  layout[29] = p.chain_wgs;
 }
 
 }  // namespace

@@ -53,6 +53,9 @@ struct RingArgs {
   // off_hin: per owned row the local id its vertex has in the previous tile of the block (uint16)
   unsigned off_chain, off_hin;
   int chain_len, u_first;
+  // chain_big >= 0 (launches over the whole plan): balanced blocks -- chain_big blocks of chain_len
+  // positions, then chain_wgs blocks of the remaining positions, equal to +-1 (tfem_rings_host.cpp)
+  int chain_big, chain_wgs;
   int flags;      // 1024: plain instead of non-temporal value stores (every build: the launch's store
                   // policy).  Ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
@@ -540,14 +543,40 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   const int clen = SRC ? a.chain_len : 1;
   const int u_end = a.u_first + a.n_tiles;
   const int block0 = SRC ? a.u_first / clen : 0;
+  // SRC, balanced blocks: the workgroup takes blocks blockIdx, blockIdx + gridDim, ... of the
+  // plan's block list -- with gridDim = chain_wgs the same number of long blocks and one short one,
+  // its equal share of the tiles -- and walks their positions one after the other
+  const bool balanced = SRC && a.chain_big >= 0;
+  int blk = int(blockIdx.x) - int(gridDim.x), blk_at = 0, blk_len = 0, blk_first = 0;
+  auto next_position = [&]() {  // -1: the workgroup's share is done
+    while (blk_at == blk_len) {
+      blk += int(gridDim.x);
+      if (blk >= a.chain_big + a.chain_wgs) return -1;
+      if (blk < a.chain_big) {
+        blk_first = blk * clen;
+        blk_len = clen;
+      } else {
+        const int rest = a.n_tiles - a.chain_big * clen, q = rest / a.chain_wgs, r = rest - q * a.chain_wgs;
+        const int w = blk - a.chain_big;
+        blk_first = a.chain_big * clen + w * q + (w < r ? w : r);
+        blk_len = q + (w < r ? 1 : 0);
+      }
+      blk_at = 0;
+    }
+    return blk_first + blk_at++;
+  };
   auto tile_at = [&](int k) {
     if constexpr (SRC != 0) {
+      ring_const_i32 order = (ring_const_i32)(uintptr_t)(a.plan + a.off_chain);
+      if (balanced) {  // called with k = 0, 1, 2, ...: the positions in the workgroup's order
+        const int u = next_position();
+        return u < 0 ? -1 : __builtin_amdgcn_readfirstlane(order[u]);
+      }
       // the workgroup of the launch's first block starts inside it when the range does
       const int k2 = k + ((xcd == 0 && j0 == 0) ? a.u_first - block0 * clen : 0);
       const int kb = k2 / clen, ki = k2 - kb * clen;
       const int u = (block0 + (j0 + kb * stride) * 8 + xcd) * clen + ki;
       if (u >= u_end) return -1;
-      ring_const_i32 order = (ring_const_i32)(uintptr_t)(a.plan + a.off_chain);
       return __builtin_amdgcn_readfirstlane(order[u]);
     } else {
       const int j = j0 + k * stride;
@@ -872,9 +901,27 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   const bool timing = DBG && (a.flags & 256);
 #endif
   unsigned long long tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // the clock the chip holds: shader cycles (s_memtime) against the constant 100 MHz counter
+  // (s_memrealtime) over the wave's whole tile loop (MI355X_MICROARCH.md, DVFS give-back item 6)
+  unsigned long long clk0 = 0, real0 = 0;
+  if (timing) {
+    clk0 = ring_stamp();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
+  }
   for (int k = 0;; ++k) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, tg = 0, tb = 0;
     if (timing) t0 = ring_stamp();
+    if (SRC) {
+      // The vector pipe serves a SIMD's OLDEST wave first: of four equally loaded workgroups on a CU
+      // the first one placed finished its loop after 100 us, the last after 190
+      // (profiles/r03_wave_loop_spread.log).  The workgroups take turns in issue priority, tile by tile.
+      switch ((k + int(blockIdx.x >> 3)) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
 #ifndef TFEM_SRC_PRIO
 #define TFEM_SRC_PRIO 0
 #endif
@@ -1068,8 +1115,12 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
     cur ^= 1;
   }
   if (timing && a.stamps && lane == 0) {
-    unsigned long long *o = a.stamps + 10 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
+    unsigned long long *o = a.stamps + 12 * (size_t(blockIdx.x) * kRingWaves + size_t(wave));
     for (int i = 0; i < 10; ++i) o[i] = tsum[i];
+    unsigned long long real1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+    o[10] = ring_stamp() - clk0;
+    o[11] = real1 - real0;
   }
 }
 

@@ -29,6 +29,26 @@ def decode_rows(rows, slots):
     return {"id": ids, "flag": flag, "pos": pos, "k": k.astype(np.int64), "dpos": dpos.astype(np.int64)}
 
 
+def chain_block_starts(plan):
+    """First position of every block of the chain order: the plan's rule (tfem_rings_host.cpp,
+    chain_block_starts), restated."""
+    n, clen, big, wgs = int(plan["n_tiles"]), int(plan["chain_len"]), int(plan["chain_big"]), int(plan["chain_wgs"])
+    starts = np.zeros(n, dtype=bool)
+    if big < 0:
+        starts[::clen] = True
+        if 0 < plan.get("n_priority", 0) < n:
+            starts[plan["n_priority"]] = True
+        return starts
+    starts[np.arange(big) * clen] = True
+    rest = n - big * clen
+    q, r = divmod(rest, wgs)
+    for w in range(wgs):
+        start, count = big * clen + w * q + min(w, r), q + (1 if w < r else 0)
+        if count > 0:
+            starts[start] = True
+    return starts
+
+
 def source_load_vector(plan, coords, source, lam, lamw, tiles=None, conn=None):
     """The load vector of a source program as the SRC launches form it: the tiles in CHAIN ORDER,
     blocks of chain_len positions per workgroup; a tile evaluates the elements of its own table
@@ -43,6 +63,8 @@ def source_load_vector(plan, coords, source, lam, lamw, tiles=None, conn=None):
     n = desc.shape[0]
     assert sorted(order.tolist()) == list(range(n)) and clen >= 1
     u0, u1 = (0, n) if tiles is None else (tiles[0], tiles[0] + tiles[1])
+    starts = chain_block_starts(plan)
+    assert tiles is None or int(plan["chain_big"]) < 0, "tile ranges: a plan with flagged vertices"
     fvec = np.full(coords.shape[0], np.nan)
     for u in range(u0, u1):
         d = desc[order[u]]
@@ -66,7 +88,7 @@ def source_load_vector(plan, coords, source, lam, lamw, tiles=None, conn=None):
         for i in range(3):
             np.add.at(acc, local[:, i], det * (fq_tile @ lamw[i]))
         hin = hand_in[row_off:row_off + n_own].astype(np.int64)
-        first_of_block = u % clen == 0 or u == u0 or u == plan.get("n_priority", 0)
+        first_of_block = bool(starts[u]) or u == u0
         if first_of_block:  # nobody hands anything to the first tile of a block or of a launch's range
             assert np.all(hin == 0xFFFF)
         else:

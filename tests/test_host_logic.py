@@ -299,6 +299,7 @@ def test_chain_blocks_evaluate_every_element_share_once(kind, chain, monkeypatch
     flags = np.zeros(nv, dtype=bool)
     flags[np.random.default_rng(11).choice(nv, 9, replace=False)] = True
     caps = dict(own_cap=64, vert_cap=160)
+    monkeypatch.setenv("TFEM_RING_WGS", "8")  # as if eight workgroups were resident: the small meshes get blocks too
     monkeypatch.setenv("TFEM_RING_CHAIN", "1")
     alone = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, **caps)
     assert alone["chain_len"] == 1 and np.all(alone["hand_in"] == 0xFFFF)
@@ -308,8 +309,25 @@ def test_chain_blocks_evaluate_every_element_share_once(kind, chain, monkeypatch
     for priority in (None, flags):
         plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=priority, **caps)
         assert plan["chain_len"] == chain
+        # without flags: balanced blocks (long ones, then one short one per workgroup); with flags
+        # (the two launches of a sharded step): blocks of `chain` positions that break between the ranges
+        starts = ring_emulator.chain_block_starts(plan)
+        assert (plan["chain_big"] >= 0) == (priority is None) and starts[0]
+        if priority is None:
+            lengths = np.diff(np.append(np.nonzero(starts)[0], plan["n_tiles"]))
+            big = plan["chain_big"]
+            wgs = plan["chain_wgs"]
+            assert wgs == 8 and big % wgs == 0 and np.all(lengths[:big] == chain)
+            share = np.zeros(wgs, dtype=np.int64)  # workgroup w takes blocks w, w + wgs, ... of the block list
+            for w in range(wgs):
+                share[w] = chain * (big // wgs)
+            rest = plan["n_tiles"] - big * chain
+            share += rest // wgs + (np.arange(wgs) < rest % wgs)
+            assert share.sum() == plan["n_tiles"] and share.max() - share.min() <= 1
         d = plan["desc"].reshape(-1, 20)
-        assert (d[:, 18] >> 8).sum() < d1[:, 17].sum() and plan["tile_tverts"].size == (d[:, 18] >> 8).sum()
+        assert plan["tile_tverts"].size == (d[:, 18] >> 8).sum() <= d1[:, 17].sum()
+        if plan["n_tiles"] >= 2 * plan["chain_wgs"]:  # enough tiles for blocks of two and more
+            assert (d[:, 18] >> 8).sum() < d1[:, 17].sum()
         n_pri, n_tiles = plan["n_priority"], plan["n_tiles"]
         order = plan["chain_order"]
         assert sorted(order[:n_pri].tolist()) == list(range(n_pri))  # the flagged tiles first in both orders

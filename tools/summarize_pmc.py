@@ -38,6 +38,7 @@ def source_sha():
 
 counters = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
 durations = defaultdict(list)
+waves = {}  # kernel -> waves of one dispatch (grid size / 64)
 for d in args.pmc:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
@@ -47,6 +48,7 @@ for d in args.pmc:
                 if args.kernel not in name:
                     continue
                 counters[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                waves[name] = int(row["Grid_Size"]) // 64
                 key = (name, row["Dispatch_Id"])
                 if key not in seen:
                     seen.add(key)
@@ -87,10 +89,19 @@ for name, cs in counters.items():
             entry["hbm_traffic_bytes_per_launch"]["cross_check_TCC_MISS_x128B"] = mean("TCC_MISS_sum") * 128.0
     if name in steady:
         entry["kernel_us_steady"] = steady[name]  # un-profiled-counter run, last 40 % of the dispatches
-    if mean("SQ_ACTIVE_INST_VALU") is not None and mean("GRBM_GUI_ACTIVE") is not None:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles with a vector instruction active, summed over the
-        # waves; one per SIMD can be active: 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / 4 is the ceiling
-        entry["valu_utilisation"] = mean("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
+    if mean("SQ_ACTIVE_INST_VALU") is not None and mean("SQ_WAVE_CYCLES") is not None and waves.get(name):
+        # Both count quad-cycles summed over the waves.  Cycles a wave lives = SQ_WAVE_CYCLES x 4 /
+        # waves (the persistent kernels' waves live from launch to end: the kernel's length in
+        # SHADER cycles -- GRBM_GUI_ACTIVE / 8 reads high on dispatches this short); cycles a SIMD's
+        # vector pipe is busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs.
+        wave_cycles = mean("SQ_WAVE_CYCLES") * 4.0 / waves[name]
+        busy = mean("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0
+        entry["waves_per_dispatch"] = waves[name]
+        entry["shader_cycles_per_wave"] = wave_cycles
+        entry["valu_busy_cycles_per_simd"] = busy
+        entry["valu_utilisation"] = busy / wave_cycles
+        if name in steady:
+            entry["shader_clock_ghz"] = wave_cycles / (steady[name]["mean"] * 1e3)
     out["kernels"][name] = entry
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)

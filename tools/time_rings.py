@@ -98,7 +98,7 @@ if "rings" in args.kernels:
     d = eng._inputs()
     nnz = int(eng.csr_structure()[1].shape[0])
     vals = torch.empty(nnz)
-    stamps = torch.zeros(10 * 4 * 4096, dtype=torch.int64)
+    stamps = torch.zeros(12 * 4 * 4096, dtype=torch.int64)
     fn = _native.load().tfem_p1_rings_debug
     fn.restype = ctypes.c_int
     names = ["A loads", "B rows", "stage", "vmcnt0", "park", "stores", "barrier"]
@@ -141,7 +141,7 @@ if "rings" in args.kernels:
                              _native.ptr(fq) if load else None, ctypes.c_int64(eng.n_elems if load else 0),
                              _native.ptr(fout) if load else None))
             torch.cuda.synchronize()
-            t = stamps.cpu().numpy().reshape(-1, 10)
+            t = stamps.cpu().numpy().reshape(-1, 12)
             t = t[t[:, 7] > 0]
             per = t[:, :7].sum(0) / t[:, 7].sum()
             print(f"  {label:18s} wg/cu={per_cu or 'max'!s:3s} " + " ".join(f"{x:8.0f}" for x in per)
