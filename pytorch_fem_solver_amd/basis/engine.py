@@ -248,9 +248,9 @@ def unpack_ring_plan(blob, layout):
         "chain_len": z[25],
         "hand_in": np.frombuffer(blob, dtype=np.uint16, count=z[1], offset=z[26]),
         "max_n_tv": z[27],
-        # z[28] >= 0: balanced blocks (that many of chain_len positions, then z[29] blocks of the rest)
-        "chain_big": z[28],
-        "chain_wgs": z[29],
+        # z[28] > 0: that many runs of the chain order, one per resident workgroup (first positions + n_tiles)
+        "n_runs": z[28],
+        "runs": np.frombuffer(blob, dtype=np.int32, count=(z[28] + 1 if z[28] > 0 else 0), offset=z[30]),
     }
 
 

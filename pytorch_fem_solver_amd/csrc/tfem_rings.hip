@@ -236,15 +236,14 @@ static int launch_rings(const RingLaunch &L) {
   // a tile's index only addresses its descriptor; the launches of a source program walk positions
   // [t_first, t_first + t_count) of the chain order instead (the same tiles for the ranges the
   // plan knows: the tiles owning flagged vertices come first in both orders)
-  a.chain_big = -1;
-  a.chain_wgs = 1;
+  a.n_runs = 0;
   if (src) {
     a.u_first = int(t_first);
-    if (z[28] >= 0 && (t_first != 0 || t_count != z[0]))
+    if (z[28] > 0 && (t_first != 0 || t_count != z[0]))
       return fail(TFEM_ERR_UNSUPPORTED, "tile ranges need a plan built with flagged vertices (its blocks break between the ranges)");
-    if (z[28] >= 0) {  // balanced blocks (plans without flagged vertices): the whole plan in one launch
-      a.chain_big = int(z[28]);
-      a.chain_wgs = int(z[29]);
+    if (z[28] > 0) {  // runs (plans without flagged vertices): the whole plan in one launch
+      a.n_runs = int(z[28]);
+      a.off_runs = unsigned(z[30]);
     }
   } else {
     a.off_desc += 80u * unsigned(t_first);
@@ -325,7 +324,7 @@ static int launch_rings(const RingLaunch &L) {
   if (src) {  // blocks of the chain order, dealt to the XCDs round-robin: workgroups per XCD that get one
     const int64_t first_block = t_first / a.chain_len, last_block = (t_first + t_count - 1) / a.chain_len;
     per = int((last_block - first_block + 1 + 7) / 8);
-    if (a.chain_big >= 0) per = (a.chain_big + a.chain_wgs + 7) / 8;
+    if (a.n_runs > 0) per = (a.n_runs + 7) / 8;
   }
   if (L.blocks_per_cu > 0 && L.blocks_per_cu < per_cu) per_cu = L.blocks_per_cu;
   // TFEM_RINGS_RESERVE_CUS: CUs per XCD this launch leaves free (a sharded step: the kernels of
@@ -371,6 +370,23 @@ static int launch_rings(const RingLaunch &L) {
                  sum[7] / (double(kRingWaves) * blocks), clk / real * 0.1, real / (double(kRingWaves) * blocks) * 0.01);
     std::fprintf(stderr, "[stamps] loop of the shortest / longest wave %.1f / %.1f us, most tiles of a wave %.0f\n",
                  real_min * 0.01, real_max * 0.01, tiles_max);
+    // who is fast: mean loop by the workgroup's place in the launch order (blocks of 256 = one per CU)
+    // and by XCD
+    std::fprintf(stderr, "[stamps] mean loop by blockIdx / 256:");
+    for (int layer = 0; layer * 256 < blocks; ++layer) {
+      double t = 0;
+      int n = 0;
+      for (int b = layer * 256; b < std::min(blocks, (layer + 1) * 256); ++b, ++n) t += double(h[12 * size_t(b) * kRingWaves + 11]);
+      std::fprintf(stderr, " %.1f", t / n * 0.01);
+    }
+    std::fprintf(stderr, " us;  by XCD (blockIdx & 7):");
+    for (int x = 0; x < 8; ++x) {
+      double t = 0;
+      int n = 0;
+      for (int b = x; b < blocks; b += 8, ++n) t += double(h[12 * size_t(b) * kRingWaves + 11]);
+      std::fprintf(stderr, " %.1f", t / n * 0.01);
+    }
+    std::fprintf(stderr, " us\n");
   }
 #endif
   if (kmat && z[23] > 0) {  // the rows of the vertices with 8 .. 15 neighbours

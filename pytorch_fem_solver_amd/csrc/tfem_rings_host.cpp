@@ -93,12 +93,16 @@ struct RingPlan {
   std::vector<int32_t> chain_order;  // position in the chain order -> tile
   std::vector<uint16_t> hand_in;     // parallel to rowstart
   int32_t chain_len = 1;
-  // chain_big >= 0: BALANCED blocks -- chain_big blocks of chain_len positions (every one of the
-  // chain_wgs resident workgroups of a launch gets the same number of them), then the remaining
-  // positions in chain_wgs blocks of equal length (+-1): a workgroup that takes blocks w, w + chain_wgs,
-  // w + 2 chain_wgs ... gets its equal share of the tiles.  chain_big < 0: blocks of chain_len
-  // positions throughout (plans with flagged vertices: the two launches of a sharded step).
-  int32_t chain_big = -1, chain_wgs = 1024;
+  // RUNS (plans without flagged vertices): the chain order is cut into chain_wgs runs, one per
+  // resident workgroup of a launch (`runs`: first position of every run, + n_tiles); a run is one
+  // block: hand-over from every tile to the next.  The runs' lengths follow `shares`: the vector
+  // pipe serves a SIMD's OLDEST wave first, so the workgroups placed first on their CUs -- the first
+  // quarter of the launch order -- progress fastest (equal shares: their loops end after 105, 127,
+  // 154 and 181 us, profiles/r03_wave_loop_spread.log) and take more tiles, so that all finish
+  // together.  No runs (plans with flagged vertices: the two launches of a sharded step): blocks of
+  // chain_len positions throughout.
+  std::vector<int32_t> runs;
+  int32_t chain_wgs = 1024;
   int32_t max_n_tv = 0;              // most elements a tile evaluates itself
 };
 
@@ -581,20 +585,53 @@ int pick_chain_len(int64_t n_tiles) {
   return 8;
 }
 
-// first position of every block: the plan's rule, which the kernel restates (tfem_rings_kernel.hpp)
-std::vector<uint8_t> chain_block_starts(int64_t n_tiles, int len, int64_t n_big, int64_t wgs, int64_t n_priority) {
+// Shares of the four quarters of the launch order (workgroups 0 .. W/4 - 1 are placed first, one
+// per CU, and are the oldest waves of their SIMDs).  Measured at S(2236) with the priorities taking
+// turns (profiles/r03_wave_loop_spread.log): equal shares 170.6 us (loops of the quarters end after
+// 137 / 148 / 156 / 165 us), 1.2 : 1.05 : 0.92 : 0.83 gives 166.7 us (159 / 153 / 147 / 147),
+// 1.3 : 1.07 : 0.88 : 0.75 gives 169.6 (172 / 157 / 143 / 137: over-corrected).
+// TFEM_RING_SHARES="a,b,c,d" overrides.
+void chain_shares(double (&share)[4]) {
+  const double measured[4] = {1.2, 1.05, 0.92, 0.83};
+  for (int i = 0; i < 4; ++i) share[i] = measured[i];
+  if (const char *v = std::getenv("TFEM_RING_SHARES")) {
+    double a, b, c, d;
+    if (std::sscanf(v, "%lf,%lf,%lf,%lf", &a, &b, &c, &d) == 4 && a > 0 && b > 0 && c > 0 && d > 0) {
+      share[0] = a;
+      share[1] = b;
+      share[2] = c;
+      share[3] = d;
+    }
+  }
+}
+
+// first position of every run (+ n_tiles): lengths proportional to the share of the run's quarter
+std::vector<int32_t> chain_runs(int64_t n_tiles, int64_t wgs) {
+  double share[4];
+  chain_shares(share);
+  std::vector<double> weight(static_cast<size_t>(wgs));
+  double total = 0;
+  for (int64_t w = 0; w < wgs; ++w) total += (weight[size_t(w)] = share[std::min<int64_t>(3, 4 * w / wgs)]);
+  std::vector<int32_t> first(size_t(wgs) + 1, 0);
+  double acc = 0;
+  for (int64_t w = 0; w < wgs; ++w) {
+    acc += weight[size_t(w)];
+    first[size_t(w) + 1] = int32_t(std::llround(double(n_tiles) * acc / total));
+  }
+  first[size_t(wgs)] = int32_t(n_tiles);
+  return first;
+}
+
+// first position of every block of hand-overs
+std::vector<uint8_t> chain_block_starts(int64_t n_tiles, int len, const std::vector<int32_t> &runs, int64_t n_priority) {
   std::vector<uint8_t> starts(size_t(n_tiles), 0);
-  if (n_big < 0) {
+  if (runs.empty()) {
     for (int64_t u = 0; u < n_tiles; u += len) starts[size_t(u)] = 1;
     if (n_priority > 0 && n_priority < n_tiles) starts[size_t(n_priority)] = 1;  // two launches: no hand-over between them
     return starts;
   }
-  for (int64_t b = 0; b < n_big; ++b) starts[size_t(b * len)] = 1;
-  const int64_t rest = n_tiles - n_big * len, q = rest / wgs, r = rest % wgs;
-  for (int64_t w = 0; w < wgs; ++w) {
-    const int64_t start = n_big * len + w * q + std::min(w, r), count = q + (w < r ? 1 : 0);
-    if (count > 0) starts[size_t(start)] = 1;
-  }
+  for (size_t w = 0; w + 1 < runs.size(); ++w)
+    if (runs[w] < runs[w + 1]) starts[size_t(runs[w])] = 1;
   return starts;
 }
 
@@ -612,10 +649,11 @@ void chain_pass(const std::vector<TileSpec> &specs, RingPlan &plan) {
   plan.chain_len = len;
   plan.chain_wgs = 1024;  // resident workgroups of a source-program launch: 4 per CU of an MI355X
   if (const char *v = std::getenv("TFEM_RING_WGS")) plan.chain_wgs = std::max(8, std::atoi(v));
-  plan.chain_big = plan.n_priority > 0 ? -1 : int32_t((n_tiles / (int64_t(plan.chain_wgs) * len)) * plan.chain_wgs);
-  if (const char *v = std::getenv("TFEM_RING_BALANCED"))
-    if (std::atoi(v) == 0) plan.chain_big = -1;
-  const std::vector<uint8_t> starts = chain_block_starts(n_tiles, len, plan.chain_big, plan.chain_wgs, plan.n_priority);
+  plan.runs.clear();
+  bool use_runs = plan.n_priority == 0;
+  if (const char *v = std::getenv("TFEM_RING_RUNS")) use_runs = use_runs && std::atoi(v) != 0;
+  if (use_runs) plan.runs = chain_runs(n_tiles, plan.chain_wgs);
+  const std::vector<uint8_t> starts = chain_block_starts(n_tiles, len, plan.runs, plan.n_priority);
   plan.hand_in.assign(plan.rowstart.size(), uint16_t(0xFFFF));
   // the blocks as ranges of positions
   std::vector<int64_t> block_first;
@@ -783,7 +821,7 @@ int build_rings(const I *conn, int64_t n_elems, int64_t n_verts, const double *c
     plan.chain_order.clear();
     plan.hand_in.clear();
     plan.chain_len = 1;
-    plan.chain_big = -1;
+    plan.runs.clear();
     plan.max_n_tv = 0;
   };
   std::vector<int32_t> vert_stamp(size_t(n_verts), -1);
@@ -988,14 +1026,15 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[5] = p.max_row_len;
   layout[6] = p.slots;
   layout[7] = p.words;
-  const int64_t bytes[10] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
+  const int64_t bytes[11] = {int64_t(p.desc.size()) * 4, int64_t(p.rows.size()) * 4,
                              int64_t(p.rowstart.size()) * 4, int64_t(p.vert_gid.size()) * 4,
                              int64_t(p.row_ecodes.size()) * 4, int64_t(p.tile_elems.size()) * 4,
                              int64_t(p.tile_tverts.size()) * 4, int64_t(p.long_rows.size()) * 4,
-                             int64_t(p.chain_order.size()) * 4, int64_t(p.hand_in.size()) * 2};
-  const int slot_of[10] = {8, 9, 10, 11, 15, 16, 20, 22, 24, 26};
+                             int64_t(p.chain_order.size()) * 4, int64_t(p.hand_in.size()) * 2,
+                             int64_t(p.runs.size()) * 4};
+  const int slot_of[11] = {8, 9, 10, 11, 15, 16, 20, 22, 24, 26, 30};
   int64_t off = 0;
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < 11; ++i) {
     layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
@@ -1009,8 +1048,7 @@ void ring_layout(const RingPlan &p, int64_t layout[kRingLayoutLen]) {
   layout[14] = p.max_n_halo;
   layout[25] = p.chain_len;
   layout[27] = p.max_n_tv;
-  layout[28] = p.chain_big;
-  layout[29] = p.chain_wgs;
+  layout[28] = p.runs.empty() ? -1 : p.chain_wgs;  // number of runs (-1: blocks of chain_len positions)
 }
 
 }  // namespace
@@ -1103,7 +1141,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
   // the arrays, each cut into pieces for the threads; the padding between them and the 64 spare
   // bytes at the end are zero
   struct Part { int64_t off; const void *src; int64_t bytes; };
-  const Part parts[10] = {
+  const Part parts[11] = {
       {layout[8], p->desc.data(), int64_t(p->desc.size()) * 4},
       {layout[9], p->rows.data(), int64_t(p->rows.size()) * 4},
       {layout[10], p->rowstart.data(), int64_t(p->rowstart.size()) * 4},
@@ -1114,6 +1152,7 @@ int tfem_ring_plan_pack(const void *plan_handle, void *blob_host) {
       {layout[22], p->long_rows.data(), int64_t(p->long_rows.size()) * 4},
       {layout[24], p->chain_order.data(), int64_t(p->chain_order.size()) * 4},
       {layout[26], p->hand_in.data(), int64_t(p->hand_in.size()) * 2},
+      {layout[30], p->runs.data(), int64_t(p->runs.size()) * 4},
   };
   for (const Part &part : parts) {
     const int64_t padded = (part.bytes + 15) & ~int64_t(15);

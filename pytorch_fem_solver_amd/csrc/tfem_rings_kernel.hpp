@@ -53,9 +53,10 @@ struct RingArgs {
   // off_hin: per owned row the local id its vertex has in the previous tile of the block (uint16)
   unsigned off_chain, off_hin;
   int chain_len, u_first;
-  // chain_big >= 0 (launches over the whole plan): balanced blocks -- chain_big blocks of chain_len
-  // positions, then chain_wgs blocks of the remaining positions, equal to +-1 (tfem_rings_host.cpp)
-  int chain_big, chain_wgs;
+  // n_runs > 0 (launches over the whole plan): the chain order in n_runs runs (off_runs: first
+  // position of every run, + the number of tiles), one per resident workgroup, a run = one block
+  int n_runs;
+  unsigned off_runs;
   int flags;      // 1024: plain instead of non-temporal value stores (every build: the launch's store
                   // policy).  Ablation build only (TFEM_RINGS_DEBUG): 1 no value stores, 2 no row arithmetic,
                   // 4 no coordinate gather, 8 no staging and stores, 16 no record loads, 32 no
@@ -543,27 +544,19 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
   const int clen = SRC ? a.chain_len : 1;
   const int u_end = a.u_first + a.n_tiles;
   const int block0 = SRC ? a.u_first / clen : 0;
-  // SRC, balanced blocks: the workgroup takes blocks blockIdx, blockIdx + gridDim, ... of the
-  // plan's block list -- with gridDim = chain_wgs the same number of long blocks and one short one,
-  // its equal share of the tiles -- and walks their positions one after the other
-  const bool balanced = SRC && a.chain_big >= 0;
-  int blk = int(blockIdx.x) - int(gridDim.x), blk_at = 0, blk_len = 0, blk_first = 0;
+  // SRC, runs: the workgroup takes runs blockIdx, blockIdx + gridDim, ... of the plan's run list (with
+  // gridDim = the number of runs: its own one) and walks their positions one after the other
+  const bool balanced = SRC && a.n_runs > 0;
+  int run = int(blockIdx.x) - int(gridDim.x), run_at = 0, run_end = 0;
   auto next_position = [&]() {  // -1: the workgroup's share is done
-    while (blk_at == blk_len) {
-      blk += int(gridDim.x);
-      if (blk >= a.chain_big + a.chain_wgs) return -1;
-      if (blk < a.chain_big) {
-        blk_first = blk * clen;
-        blk_len = clen;
-      } else {
-        const int rest = a.n_tiles - a.chain_big * clen, q = rest / a.chain_wgs, r = rest - q * a.chain_wgs;
-        const int w = blk - a.chain_big;
-        blk_first = a.chain_big * clen + w * q + (w < r ? w : r);
-        blk_len = q + (w < r ? 1 : 0);
-      }
-      blk_at = 0;
+    while (run_at == run_end) {
+      run += int(gridDim.x);
+      if (run >= a.n_runs) return -1;
+      ring_const_i32 first = (ring_const_i32)(uintptr_t)(a.plan + a.off_runs);
+      run_at = first[run];
+      run_end = first[run + 1];
     }
-    return blk_first + blk_at++;
+    return run_at++;
   };
   auto tile_at = [&](int k) {
     if constexpr (SRC != 0) {
@@ -915,7 +908,10 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
       // The vector pipe serves a SIMD's OLDEST wave first: of four equally loaded workgroups on a CU
       // the first one placed finished its loop after 100 us, the last after 190
       // (profiles/r03_wave_loop_spread.log).  The workgroups take turns in issue priority, tile by tile.
-      switch ((k + int(blockIdx.x >> 3)) & 3) {
+#ifndef TFEM_SRC_PRIO_SHIFT
+#define TFEM_SRC_PRIO_SHIFT 3
+#endif
+      switch (TFEM_SRC_PRIO_SHIFT < 0 ? 0 : (k + int(blockIdx.x >> (TFEM_SRC_PRIO_SHIFT < 0 ? 0 : TFEM_SRC_PRIO_SHIFT))) & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;

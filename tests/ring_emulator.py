@@ -30,22 +30,19 @@ def decode_rows(rows, slots):
 
 
 def chain_block_starts(plan):
-    """First position of every block of the chain order: the plan's rule (tfem_rings_host.cpp,
-    chain_block_starts), restated."""
-    n, clen, big, wgs = int(plan["n_tiles"]), int(plan["chain_len"]), int(plan["chain_big"]), int(plan["chain_wgs"])
+    """First position of every block of hand-overs: the runs of the plan (one per resident
+    workgroup), or -- plans with flagged vertices -- blocks of chain_len positions that break between
+    the two launch ranges."""
+    n, clen = int(plan["n_tiles"]), int(plan["chain_len"])
     starts = np.zeros(n, dtype=bool)
-    if big < 0:
+    if int(plan["n_runs"]) <= 0:
         starts[::clen] = True
         if 0 < plan.get("n_priority", 0) < n:
             starts[plan["n_priority"]] = True
         return starts
-    starts[np.arange(big) * clen] = True
-    rest = n - big * clen
-    q, r = divmod(rest, wgs)
-    for w in range(wgs):
-        start, count = big * clen + w * q + min(w, r), q + (1 if w < r else 0)
-        if count > 0:
-            starts[start] = True
+    runs = plan["runs"]
+    assert runs[0] == 0 and runs[-1] == n and np.all(np.diff(runs) >= 0)
+    starts[runs[:-1][np.diff(runs) > 0]] = True
     return starts
 
 
@@ -64,7 +61,7 @@ def source_load_vector(plan, coords, source, lam, lamw, tiles=None, conn=None):
     assert sorted(order.tolist()) == list(range(n)) and clen >= 1
     u0, u1 = (0, n) if tiles is None else (tiles[0], tiles[0] + tiles[1])
     starts = chain_block_starts(plan)
-    assert tiles is None or int(plan["chain_big"]) < 0, "tile ranges: a plan with flagged vertices"
+    assert tiles is None or int(plan["n_runs"]) <= 0, "tile ranges: a plan with flagged vertices"
     fvec = np.full(coords.shape[0], np.nan)
     for u in range(u0, u1):
         d = desc[order[u]]

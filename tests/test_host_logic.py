@@ -299,34 +299,35 @@ def test_chain_blocks_evaluate_every_element_share_once(kind, chain, monkeypatch
     flags = np.zeros(nv, dtype=bool)
     flags[np.random.default_rng(11).choice(nv, 9, replace=False)] = True
     caps = dict(own_cap=64, vert_cap=160)
-    monkeypatch.setenv("TFEM_RING_WGS", "8")  # as if eight workgroups were resident: the small meshes get blocks too
+    monkeypatch.setenv("TFEM_RING_WGS", "8")  # as if eight workgroups were resident: the small meshes get runs of several tiles
+    monkeypatch.setenv("TFEM_RING_RUNS", "0")
     monkeypatch.setenv("TFEM_RING_CHAIN", "1")
     alone = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, **caps)
-    assert alone["chain_len"] == 1 and np.all(alone["hand_in"] == 0xFFFF)
+    assert alone["chain_len"] == 1 and alone["n_runs"] <= 0 and np.all(alone["hand_in"] == 0xFFFF)
     d1 = alone["desc"].reshape(-1, 20)
     assert np.array_equal(d1[:, 18] >> 8, d1[:, 17])  # no blocks: every tile evaluates all of its elements
     monkeypatch.setenv("TFEM_RING_CHAIN", str(chain))
-    for priority in (None, flags):
+    for runs, priority in ((True, None), (False, None), (False, flags)):
+        monkeypatch.setenv("TFEM_RING_RUNS", "1" if runs else "0")
         plan = ring_plan_host(mesh["triangles"], nv, mesh["vertices"], rowptr, colind, priority=priority, **caps)
         assert plan["chain_len"] == chain
-        # without flags: balanced blocks (long ones, then one short one per workgroup); with flags
-        # (the two launches of a sharded step): blocks of `chain` positions that break between the ranges
+        # runs (the default without flags): one run of the chain order per resident workgroup, hand-over
+        # from every tile to the next; blocks (with flags: the two launches of a sharded step): `chain`
+        # positions each, breaking between the ranges
         starts = ring_emulator.chain_block_starts(plan)
-        assert (plan["chain_big"] >= 0) == (priority is None) and starts[0]
-        if priority is None:
-            lengths = np.diff(np.append(np.nonzero(starts)[0], plan["n_tiles"]))
-            big = plan["chain_big"]
-            wgs = plan["chain_wgs"]
-            assert wgs == 8 and big % wgs == 0 and np.all(lengths[:big] == chain)
-            share = np.zeros(wgs, dtype=np.int64)  # workgroup w takes blocks w, w + wgs, ... of the block list
-            for w in range(wgs):
-                share[w] = chain * (big // wgs)
-            rest = plan["n_tiles"] - big * chain
-            share += rest // wgs + (np.arange(wgs) < rest % wgs)
-            assert share.sum() == plan["n_tiles"] and share.max() - share.min() <= 1
+        assert (plan["n_runs"] > 0) == runs and starts[0]
+        if runs:
+            first = plan["runs"]
+            assert plan["n_runs"] == 8 and first.size == 9 and first[0] == 0 and first[-1] == plan["n_tiles"]
+            # the first quarter of the launch order (the oldest waves of their SIMDs: served first by the
+            # vector pipe) takes more tiles than the last: 1.2 : 1.05 : 0.92 : 0.83
+            lengths = np.diff(first)
+            if plan["n_tiles"] >= 64:  # rounding aside
+                assert lengths[:2].sum() >= lengths[2:4].sum() >= lengths[4:6].sum() >= lengths[6:].sum()
+            assert lengths.max() - lengths.min() <= max(2, int(0.45 * lengths.mean()) + 1)
         d = plan["desc"].reshape(-1, 20)
         assert plan["tile_tverts"].size == (d[:, 18] >> 8).sum() <= d1[:, 17].sum()
-        if plan["n_tiles"] >= 2 * plan["chain_wgs"]:  # enough tiles for blocks of two and more
+        if plan["n_tiles"] >= 2 * 8:  # enough tiles for runs / blocks of two and more
             assert (d[:, 18] >> 8).sum() < d1[:, 17].sum()
         n_pri, n_tiles = plan["n_priority"], plan["n_tiles"]
         order = plan["chain_order"]
@@ -870,10 +871,10 @@ def test_host_builders_do_not_depend_on_the_thread_count_and_keep_their_digest()
 
     delaunay = meshgen.delaunay_square(30000, 3)
     cases = {
-        "S300": (meshgen.unit_square(300, 0.25, 0), "5a04cc60528a1596", "9b34763e1a02eab9"),
+        "S300": (meshgen.unit_square(300, 0.25, 0), "930b517c9fc6f46d", "9b34763e1a02eab9"),
         "Dmorton": (meshgen.permute_mesh(delaunay, vertex_order=meshgen.morton_order(delaunay["vertices"])),
-                    "64a75dbc3cf7c485", None),
-        "Dnative": (delaunay, "3af7e622040c38a6", None),
+                    "933aa0a07a1e75fb", None),
+        "Dnative": (delaunay, "194f141ce0e7b301", None),
     }
     saved = os.environ.get("TFEM_HOST_THREADS")
     saved_long = os.environ.get("TFEM_RING_LONG")
