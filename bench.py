@@ -636,7 +636,7 @@ def main():
                 "kernel_ms": k_ms,
                 "kernel_ms_probed": k_ms_probed,
                 "launch": "fused K + f with the source evaluated in the launch (52 B/element algorithmic, "
-                "SURVEY.md 8(d)); the launch is bound by fp64 vector issue, not by HBM: DESIGN.md section 3"
+                "SURVEY.md 8(d)); the launch is bound by fp64 vector issue (76.9 M wave-instructions at 2.3-2.4 GHz), not by HBM: DESIGN.md sections 0 and 3"
                 + ("" if world == 1 else "; N > 1: kernel_ms = wall clock of the timed region / steps (two streams and a "
                    "collective per step), achieved = this rank's algorithmic bytes over it"),
                 "stiffness_only": {
@@ -674,8 +674,7 @@ def main():
                 if profile["fused"] else "no committed profile of these kernel sources: traffic not quoted")
             # the same work through the reference's public API, per call: tracer + two launches
             def api_step():
-                basis.integrate_bilinear_form(stiffness_form, layout="csr")
-                basis.integrate_linear_form(load_form)
+                basis.assemble_system(stiffness_form, load_form, layout="csr")
 
             for _ in range(20):
                 api_step()
@@ -685,8 +684,21 @@ def main():
                 api_step()
             torch.cuda.synchronize()
             line["api_ms_per_step"] = (time.perf_counter() - t1) * 1e3 / 100
-            line["api_note"] = ("integrate_bilinear_form(v_grad @ v_grad.mT, layout='csr') + integrate_linear_form("
-                                "f(x_q) * v) per call at this mesh: tracer, K launch, f launch with the source inside")
+            line["api_note"] = ("Basis.assemble_system(v_grad @ v_grad.mT, f(x_q) * v, layout='csr') per call at this mesh: "
+                                "both callables traced, ONE fused launch with the source inside")
+
+            def api_two_calls():
+                basis.integrate_bilinear_form(stiffness_form, layout="csr")
+                basis.integrate_linear_form(load_form)
+
+            for _ in range(10):
+                api_two_calls()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                api_two_calls()
+            torch.cuda.synchronize()
+            line["api_two_calls_ms_per_step"] = (time.perf_counter() - t1) * 1e3 / 50
         if world == 1 and not args.no_other_configs:
             # the same launch with other sources: what the source itself costs (the launch is
             # bound by fp64 vector issue), and with pre-evaluated source values

@@ -89,19 +89,17 @@ for name, cs in counters.items():
             entry["hbm_traffic_bytes_per_launch"]["cross_check_TCC_MISS_x128B"] = mean("TCC_MISS_sum") * 128.0
     if name in steady:
         entry["kernel_us_steady"] = steady[name]  # un-profiled-counter run, last 40 % of the dispatches
-    if mean("SQ_ACTIVE_INST_VALU") is not None and mean("SQ_WAVE_CYCLES") is not None and waves.get(name):
-        # Both count quad-cycles summed over the waves.  Cycles a wave lives = SQ_WAVE_CYCLES x 4 /
-        # waves (the persistent kernels' waves live from launch to end: the kernel's length in
-        # SHADER cycles -- GRBM_GUI_ACTIVE / 8 reads high on dispatches this short); cycles a SIMD's
-        # vector pipe is busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs.
-        wave_cycles = mean("SQ_WAVE_CYCLES") * 4.0 / waves[name]
+    if mean("SQ_ACTIVE_INST_VALU") is not None:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles with a vector instruction in a SIMD's pipe, summed over
+        # the waves: x 4 / 1024 SIMDs = cycles a SIMD's vector pipe is busy per dispatch.  Against the
+        # kernel's length at the clock the chip holds (2.26-2.40 GHz by in-kernel s_memtime /
+        # s_memrealtime stamps, profiles/r03_wave_loop_spread.log; GRBM_GUI_ACTIVE / 8 reads high on
+        # dispatches this short, SQ_WAVE_CYCLES does not cover a wave's whole life).
         busy = mean("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0
-        entry["waves_per_dispatch"] = waves[name]
-        entry["shader_cycles_per_wave"] = wave_cycles
         entry["valu_busy_cycles_per_simd"] = busy
-        entry["valu_utilisation"] = busy / wave_cycles
         if name in steady:
-            entry["shader_clock_ghz"] = wave_cycles / (steady[name]["mean"] * 1e3)
+            entry["valu_utilisation"] = busy / (steady[name]["mean"] * 1e3 * 2.35)
+            entry["valu_utilisation_note"] = "busy cycles / (steady kernel time x 2.35 GHz, the in-kernel clock)"
     out["kernels"][name] = entry
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)
