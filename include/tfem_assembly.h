@@ -481,7 +481,8 @@ int tfem_p1_residual_backward(const void *coords, int real_bytes, const void *co
  *           vertex tile [7],[8] local vertices listed for vertex / edge tiles
  *           [10..15] byte offsets of desc, rows, vert_gid of the vertex tiles and of the edge
  *           tiles in the packed plan [16] bytes of the packed plan [17] byte offset and [18] number
- *           of the long vertex rows (32-dword records)
+ *           of the long vertex rows (32-dword records) [19..21] element codes of the load-vector
+ *           launch (tfem_p2_load_rows)
  *   pack  : record and descriptor layout: csrc/tfem_p2rows_host.cpp
  * ------------------------------------------------------------------------- */
 int tfem_p2_plan_create(const int32_t *conn_dof_host, int64_t n_elems, int64_t n_verts,
@@ -495,6 +496,17 @@ void tfem_p2_plan_destroy(void *plan);
 int tfem_p2_assemble_rows(const void *coords, int real_bytes, int quad_order, double alpha,
                           double beta, const void *plan_device, const int64_t *plan_layout_host,
                           void *vals, int64_t nnz, void *stream);
+/* The P2 load vector in ROW form over the same plan (replaces integrate_linear_form of f v for
+ * ElementTri(2, .): abstract_basis.py:95-112, element_tri.py:43-70, dx of basis.py:93-96):
+ *   out[r] = sum over the triangles T of DoF r of det_T * sum_q fq[T][q] phi_loc(q) w_q / 2
+ * fq (n_elems, Q) source values at the integration points of the elements in their stored frame,
+ * out (n_dofs) written exactly once per DoF (launches: vertex rows, long vertex rows if any, edge
+ * rows); no atomics, no element vectors.  The plan's layout[19], [20], [21]: byte offsets of the
+ * element codes (element * 4 + local index of the DoF among the three of its kind) of the vertex
+ * rows (8 dwords per row), the edge rows (2 dwords) and the long rows (16 dwords). */
+int tfem_p2_load_rows(const void *coords, int real_bytes, int quad_order, const void *plan_device,
+                      const int64_t *plan_layout_host, const void *fq, int64_t n_elems, void *out,
+                      int64_t n_dofs, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Interface exchange of the multi-GPU sharding (DEVICE; the path shards by element

@@ -135,6 +135,9 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     ),
+    "tfem_p2_load_rows": (
+        c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p],
+    ),
     "tfem_csr_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "tfem_edge_interpolate_p1": (
         c_int,

@@ -288,6 +288,10 @@ def p2_plan_host(conn_dof, n_verts, n_dofs, coords, rowptr, colind):
         "edge": {"desc": view(3, np.int32, 16 * z[1]), "rows": view(4, np.uint32, 4 * z[3]),
                  "vert_gid": view(5, np.int32, z[8])},
         "long_rows": np.frombuffer(blob, dtype=np.uint32, count=32 * z[18], offset=z[17]),
+        # load vector in row form: element * 4 + local index per fan slot / per triangle of an edge
+        "vertex_codes": np.frombuffer(blob, dtype=np.uint32, count=8 * z[2], offset=z[19]),
+        "edge_codes": np.frombuffer(blob, dtype=np.uint32, count=2 * z[3], offset=z[20]),
+        "long_codes": np.frombuffer(blob, dtype=np.uint32, count=16 * z[18], offset=z[21]),
     }
 
 
@@ -1241,6 +1245,19 @@ class AssemblyEngine:
             return self._assemble_tiles(0.0, 0.0, want_matrix=False, fq=fq)[1]
         d = self._inputs()
         fq = fq.to(self.device, self.dtype).reshape(self.n_elems, self.n_quad).contiguous()
+        if self.p2_plan() is not None and os.environ.get("TFEM_P2_LOAD", "rows") == "rows":
+            # P2 with a row plan: one lane per DoF over the tiles of the stiffness launch
+            rows = self.p2_plan()
+            out = torch.empty(self.n_dofs, dtype=self.dtype, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(
+                    self.lib.tfem_p2_load_rows(
+                        _native.ptr(d["coords"]), self.real_bytes, self.quad_order, _native.ptr(rows["blob"]),
+                        c_void_p(rows["layout"].ctypes.data), _native.ptr(fq), self.n_elems, _native.ptr(out),
+                        self.n_dofs, self._stream(),
+                    )
+                )
+            return out
         # P2, fractures, meshes without a plan: element vectors -> gather (no atomics, the
         # reference's accumulation order); TFEM_KERNEL=atomic keeps the one-pass atomic scatter
         two_pass = self.kernel != "atomic"

@@ -35,6 +35,10 @@
 //   w1 : local id d | has2 << 10 | rev << 11 (triangle 2's frame starts at b: (b, a, d))
 //   w2 : positions, 4 bits each: a, b, c, self, edge (b,c), edge (c,a), d, edge (b2,d)
 //   w3 : position of edge (d,a2)
+// Element codes (load vector in row form, tfem_p2load.hip), in the order of the records: per fan
+//   slot of a vertex row (8 dwords per row; 16 per long row) and per triangle of an edge row (2
+//   dwords) element * 4 + the local index of the row's DoF among the three DoFs of its kind in that
+//   element (0xFFFFFFFF: no triangle).
 // Descriptor (16 ints per tile): vert_off, n_vert, row_off, 0, first row of wave 1, 2, 3,
 //   n_own, vertex id of the first row of wave 0..3 (vertex tiles), CSR offset of the first
 //   row of wave 0..3.
@@ -58,6 +62,10 @@ struct P2Plan {
   std::vector<uint32_t> rows[2];
   std::vector<int32_t> vert_gid[2];
   std::vector<uint32_t> long_rows;  // 32 dwords per vertex with 8 .. 15 neighbours
+  // load vector in row form (tfem_p2_load_rows): per fan slot / per triangle of an edge the element
+  // and the local index the row's DoF has in it, element * 4 + index (0xFFFFFFFF: no triangle);
+  // 8 dwords per vertex row, 2 per edge row, 16 per long row, in the order of the row records
+  std::vector<uint32_t> codes[2], long_codes;
   int32_t max_n_vert[2] = {0, 0}, max_n_halo = 0;
   int64_t n_tiles[2] = {0, 0};
   int64_t n_verts = 0, n_edges = 0;
@@ -73,6 +81,7 @@ struct P2Fan {
   int flag[kP2FanMax + 1];
   int32_t edge_v[kP2FanMax + 1];    // DoF of edge (v, n_i)
   int32_t edge_op[kP2FanMax + 1];   // DoF of the edge opposite to v in slot i's triangle (-1: none)
+  uint32_t code[kP2FanMax + 1];     // slot i's triangle: element * 4 + local index of v (0xFFFFFFFF: none)
 };
 
 // Fan of vertex v from its incident elements (conn6: three vertices, three edge DoFs).
@@ -83,6 +92,7 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
   if (nt == 0) return true;
   if (nt > kP2FanMax) return false;
   int32_t ta[kP2FanMax + 1], tb[kP2FanMax + 1], tea[kP2FanMax + 1], teo[kP2FanMax + 1], teb[kP2FanMax + 1];
+  int tj[kP2FanMax + 1];
   int32_t nb[kP2FanMax + 2], nb_edge[kP2FanMax + 2];
   int cnt[kP2FanMax + 2], tri[kP2FanMax + 2][2];
   int n_nb = 0;
@@ -95,6 +105,7 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
         ++hits;
       }
     if (hits != 1) return false;
+    tj[t] = j;
     ta[t] = c[(j + 1) % 3];
     tb[t] = c[(j + 2) % 3];
     tea[t] = c[3 + j];            // edge (v, a)
@@ -136,6 +147,7 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
       fan.edge_v[fan.k] = nb_edge[c];
       fan.flag[fan.k] = 0;
       fan.edge_op[fan.k] = -1;
+      fan.code[fan.k] = 0xFFFFFFFFu;
       int t = -1;
       for (int s = 0; s < cnt[c]; ++s)
         if (!used[tri[c][s]]) {
@@ -150,6 +162,7 @@ bool build_p2_fan(const int32_t *conn6, int32_t v, const int32_t *adj_first, con
       const bool forward = ta[t] == nb[c];
       fan.flag[fan.k] = forward ? 1 : 2;
       fan.edge_op[fan.k] = teo[t];
+      fan.code[fan.k] = uint32_t(adj_first[t]) * 4u + uint32_t(tj[t]);
       ++fan.k;
       const int o = index_of(forward ? tb[t] : ta[t]);
       if (seen[o]) return o;
@@ -400,6 +413,10 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
           if (!ok) return fail(TFEM_ERR_INVALID_ARGUMENT, "row %d: a column is missing from the CSR pattern", u);
           plan.long_rows.insert(plan.long_rows.end(), r, r + 32);
           plan.rows[0].insert(plan.rows[0].end(), w, w + 8);
+          uint32_t lc[16];
+          for (int i = 0; i < 16; ++i) lc[i] = i < fan.k ? fan.code[i] : 0xFFFFFFFFu;
+          plan.long_codes.insert(plan.long_codes.end(), lc, lc + 16);
+          plan.codes[0].insert(plan.codes[0].end(), 8, 0xFFFFFFFFu);
           continue;
         }
         uint32_t field[21] = {0};
@@ -415,6 +432,9 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
         if (!ok) return fail(TFEM_ERR_INVALID_ARGUMENT, "row %d: a column is missing from the CSR pattern", u);
         for (int f = 0; f < 21; ++f) w[3 + f / 6] |= field[f] << (5 * (f % 6));
         plan.rows[0].insert(plan.rows[0].end(), w, w + 8);
+        uint32_t vc[8];
+        for (int i = 0; i < 8; ++i) vc[i] = i < fan.k ? fan.code[i] : 0xFFFFFFFFu;
+        plan.codes[0].insert(plan.codes[0].end(), vc, vc + 8);
       }
       int32_t d[16] = {vert_off, next_local, row_off, 0, ws[1], ws[2], ws[3], n_own, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int w = 0; w < 4; ++w)
@@ -513,6 +533,8 @@ int build_p2(const int32_t *conn6, int64_t n_elems, int64_t n_verts, int64_t n_d
         for (int f = 0; f < 8; ++f) w[2] |= pos[f] << (4 * f);
         w[3] = pos[8];
         plan.rows[1].insert(plan.rows[1].end(), w, w + 4);
+        plan.codes[1].push_back(uint32_t(te1));
+        plan.codes[1].push_back(te2 >= 0 ? uint32_t(te2) : 0xFFFFFFFFu);
       }
       int32_t d[16] = {vert_off, n_local, row_off, 0, ws[1], ws[2], ws[3], n_own, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int w = 0; w < 4; ++w)
@@ -541,13 +563,14 @@ void p2_layout(const P2Plan &p, int64_t layout[kP2LayoutLen]) {
   layout[6] = p.max_n_halo;
   layout[7] = int64_t(p.vert_gid[0].size());
   layout[8] = int64_t(p.vert_gid[1].size());
-  const int64_t bytes[7] = {int64_t(p.desc[0].size()) * 4, int64_t(p.rows[0].size()) * 4,
-                            int64_t(p.vert_gid[0].size()) * 4, int64_t(p.desc[1].size()) * 4,
-                            int64_t(p.rows[1].size()) * 4, int64_t(p.vert_gid[1].size()) * 4,
-                            int64_t(p.long_rows.size()) * 4};
-  const int slot_of[7] = {10, 11, 12, 13, 14, 15, 17};
+  const int64_t bytes[10] = {int64_t(p.desc[0].size()) * 4, int64_t(p.rows[0].size()) * 4,
+                             int64_t(p.vert_gid[0].size()) * 4, int64_t(p.desc[1].size()) * 4,
+                             int64_t(p.rows[1].size()) * 4, int64_t(p.vert_gid[1].size()) * 4,
+                             int64_t(p.long_rows.size()) * 4, int64_t(p.codes[0].size()) * 4,
+                             int64_t(p.codes[1].size()) * 4, int64_t(p.long_codes.size()) * 4};
+  const int slot_of[10] = {10, 11, 12, 13, 14, 15, 17, 19, 20, 21};
   int64_t off = 0;
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < 10; ++i) {
     layout[slot_of[i]] = off;
     off += (bytes[i] + 15) & ~int64_t(15);
   }
@@ -603,6 +626,9 @@ int tfem_p2_plan_pack(const void *plan_handle, void *blob_host) {
   std::memcpy(out + layout[14], p->rows[1].data(), p->rows[1].size() * 4);
   std::memcpy(out + layout[15], p->vert_gid[1].data(), p->vert_gid[1].size() * 4);
   std::memcpy(out + layout[17], p->long_rows.data(), p->long_rows.size() * 4);
+  std::memcpy(out + layout[19], p->codes[0].data(), p->codes[0].size() * 4);
+  std::memcpy(out + layout[20], p->codes[1].data(), p->codes[1].size() * 4);
+  std::memcpy(out + layout[21], p->long_codes.data(), p->long_codes.size() * 4);
   return TFEM_OK;
 }
 

@@ -166,3 +166,90 @@ def run_p2_plan(plan, coords, rowptr, n_verts, integration_order=2, alpha=1.0, b
             if ws[wv] < ws[wv + 1]:
                 assert d[8 + wv] == first + ws[wv] and d[12 + wv] == rowptr[first + ws[wv]]
     return vals, writes
+
+
+def load_tables(integration_order):
+    """(6, Q): phi_a(q) * w_q / 2 -- what a row multiplies the source values of a triangle with."""
+    nodes, weights = orc.gauss_rule(integration_order)
+    bary = orc.barycentric_coordinates(nodes)
+    phi, _ = orc.shape_functions(2, bary, np.eye(2))
+    return (np.asarray(phi).reshape(-1, 6) * (0.5 * np.asarray(weights).reshape(-1, 1))).T
+
+
+def run_p2_load_plan(plan, coords, n_verts, n_dofs, fq, integration_order=2):
+    """The load vector as k_p2_load_rows / k_p2_load_long_rows form it (csrc/tfem_p2load.hip): per row
+    the triangles of the stiffness record, the element and the DoF's local index from the codes
+    (element * 4 + index among the three DoFs of the row's kind).  Returns (f, writes)."""
+    tab = load_tables(integration_order)
+    f = np.full(n_dofs, np.nan)
+    writes = np.zeros(n_dofs, dtype=np.int64)
+    none = 0xFFFFFFFF
+
+    def share(code, base, p0, p1, p2):
+        e1, e2 = p1 - p0, p2 - p0
+        return (e1[0] * e2[1] - e1[1] * e2[0]) * float(fq[code >> 2] @ tab[base + (code & 3)])
+
+    part = plan["vertex"]
+    rows = part["rows"].reshape(-1, 8).astype(np.uint64)
+    codes = plan["vertex_codes"].reshape(-1, 8)
+    assert codes.shape[0] == rows.shape[0]
+    for d in part["desc"].reshape(-1, 16):
+        vert_off, n_vert, row_off, n_own = int(d[0]), int(d[1]), int(d[2]), int(d[7])
+        gid = part["vert_gid"][vert_off:vert_off + n_vert]
+        xy = coords[gid]
+        for r in range(n_own):
+            w, c = rows[row_off + r], codes[row_off + r]
+            k = int((w[2] >> np.uint64(24)) & np.uint64(7))
+            v = int(gid[r])
+            if k == 0 and int(w[3] >> np.uint64(31)):
+                assert np.all(c == none)
+                continue
+            ids = [int((w[i // 3] >> np.uint64(10 * (i % 3))) & np.uint64(0x3FF)) for i in range(k)]
+            flags = [int((w[2] >> np.uint64(10 + 2 * i)) & np.uint64(3)) for i in range(k)]
+            acc = 0.0
+            for i in range(8):
+                if i >= k or flags[i] == 0:
+                    assert c[i] == none
+                    continue
+                nxt = 0 if i + 1 == k else i + 1
+                p1, p2 = (xy[ids[i]], xy[ids[nxt]]) if flags[i] == 1 else (xy[ids[nxt]], xy[ids[i]])
+                acc += share(int(c[i]), 0, xy[r], p1, p2)
+            f[v] = acc
+            writes[v] += 1
+    long_rows = plan["long_rows"].reshape(-1, 32).astype(np.uint64)
+    long_codes = plan["long_codes"].reshape(-1, 16)
+    assert long_codes.shape[0] == long_rows.shape[0]
+    for r, c in zip(long_rows, long_codes):
+        v, k, flagword = int(r[0]), int(r[2] & np.uint64(0xFF)), int(r[3])
+        ids = [int(r[4 + i]) for i in range(k)]
+        acc = 0.0
+        for i in range(16):
+            flag = (flagword >> (2 * i)) & 3 if i < k else 0
+            if flag == 0:
+                assert c[i] == none
+                continue
+            nxt = 0 if i + 1 == k else i + 1
+            p1, p2 = (coords[ids[i]], coords[ids[nxt]]) if flag == 1 else (coords[ids[nxt]], coords[ids[i]])
+            acc += share(int(c[i]), 0, coords[v], p1, p2)
+        f[v] = acc
+        writes[v] += 1
+    part = plan["edge"]
+    rows = part["rows"].reshape(-1, 4).astype(np.uint64)
+    codes = plan["edge_codes"].reshape(-1, 2)
+    assert codes.shape[0] == rows.shape[0]
+    for d in part["desc"].reshape(-1, 16):
+        vert_off, n_vert, row_off, n_own, first = int(d[0]), int(d[1]), int(d[2]), int(d[7]), int(d[8])
+        xy = coords[part["vert_gid"][vert_off:vert_off + n_vert]]
+        for r in range(n_own):
+            w, c = rows[row_off + r], codes[row_off + r]
+            a, b, cc = (int((w[0] >> np.uint64(s)) & np.uint64(0x3FF)) for s in (0, 10, 20))
+            dd = int(w[1] & np.uint64(0x3FF))
+            has2, rev = bool((w[1] >> np.uint64(10)) & np.uint64(1)), bool((w[1] >> np.uint64(11)) & np.uint64(1))
+            acc = share(int(c[0]), 3, xy[a], xy[b], xy[cc])
+            assert (c[1] != none) == has2
+            if has2:
+                o, t = (xy[b], xy[a]) if rev else (xy[a], xy[b])
+                acc += share(int(c[1]), 3, o, t, xy[dd])
+            f[first + r] = acc
+            writes[first + r] += 1
+    return f, writes

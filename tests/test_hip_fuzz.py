@@ -150,8 +150,13 @@ def test_random_p2_meshes_every_kernel_mode(seed, monkeypatch):
         vals = _caller_values(eng, eng.bilinear(alpha, beta))
         assert scaled_error(vals.cpu().numpy(), want) <= 1e-12, (seed, kernel, eng.kernel_name())
         fq = torch.tensor(np.cos(np.arange(tris.shape[0] * eng.n_quad)).reshape(tris.shape[0], -1))
+        # the load vector of every mode (auto: row form over the P2 plan where it exists) against the oracle's
+        local_f = orc.integrate_local(fq.cpu().numpy().reshape(-1, eng.n_quad, 1, 1) * geo["v"], geo["dx"])
+        want_f = orc.assemble_linear(local_f, conn6, xy.shape[0]).reshape(-1)
+        got_f = eng.load(fq).cpu().numpy().reshape(-1)
+        assert scaled_error(got_f, want_f) <= 1e-12, (seed, kernel, "load")
         if kernel == "auto":  # per-DoF vectors leave the engine in the caller's numbering
-            loads[eng.renumbered] = eng.load(fq).cpu().numpy()
+            loads[eng.renumbered] = got_f
     if True in loads:  # the same vector as the engine gives without its renumbering
         monkeypatch.setenv("TFEM_RENUMBER", "0")
         plain = AssemblyEngine(torch.tensor(mesh["vertices"]), torch.tensor(tris), torch.tensor(conn6), xy.shape[0], 2, order)

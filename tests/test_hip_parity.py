@@ -958,6 +958,64 @@ def test_p2_row_kernels_against_oracle_and_gather(dtype, form, order, mesh_kind)
     assert scaled_error(got["rows"].cpu().double(), got["gather"].cpu().double()) <= (1e-13 if dtype == torch.float64 else 2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+@pytest.mark.parametrize("mesh_kind", ["structured", "delaunay_morton", "holes"])
+def test_p2_load_rows_against_oracle_and_gather(dtype, order, mesh_kind, monkeypatch):
+    """k_p2_load_rows / k_p2_load_long_rows (the P2 load vector in row form: one lane per DoF over the
+    tiles of the stiffness launch, element codes from the plan) on meshes stored with mixed
+    orientation, with source values that differ from point to point: equal to the oracle's
+    `(f v dx).sum(-3)` + `index_put_(accumulate=True)` (abstract_basis.py:95-112) entry by entry
+    and to the element-vector + gather path.  holes: removed elements -- open fans, edges with one
+    triangle, isolated vertices (rows without a triangle are written as zeros)."""
+    from pytorch_fem_solver_amd import dofs, meshgen
+
+    torch.set_default_dtype(dtype)
+    tol = TOL if dtype == torch.float64 else 2e-5
+    if mesh_kind == "delaunay_morton":
+        native = meshgen.delaunay_square(6000, 7)
+        mesh_np = meshgen.permute_mesh(native, vertex_order=meshgen.morton_order(native["vertices"]))
+    else:
+        mesh_np = meshgen.unit_square(70, 0.25, 4)
+    tri = mesh_np["triangles"].copy()
+    rng = np.random.default_rng(11)
+    if mesh_kind == "holes":
+        tri = tri[rng.random(tri.shape[0]) >= 0.1]
+    flip = rng.random(tri.shape[0]) < 0.4
+    tri[flip] = tri[flip][:, [0, 2, 1]]
+    edges, on_boundary = meshgen._edges_from_triangles(tri)
+    conn6, xy, _ = dofs.p2_dofs_numpy(mesh_np["vertices"], tri, edges, on_boundary.astype(np.int32).reshape(-1, 1),
+                                      mesh_np["vertex_markers"])
+    from pytorch_fem_solver_amd.basis.engine import AssemblyEngine
+
+    verts = mesh_np["vertices"] if dtype == torch.float64 else mesh_np["vertices"].astype(np.float32)
+    geo = orc.geometry(verts[tri], 2, order)
+    nq = geo["dx"].shape[1]
+    fq_np = rng.uniform(-1.0, 2.0, size=(tri.shape[0], nq)).astype(verts.dtype)
+    got = {}
+    for path in ("rows", "gather"):
+        monkeypatch.setenv("TFEM_P2_LOAD", path)
+        eng = AssemblyEngine(torch.tensor(mesh_np["vertices"]), torch.tensor(tri), torch.tensor(conn6), xy.shape[0], 2, order)
+        assert eng.p2_plan() is not None
+        calls = []
+        inner = eng.lib.tfem_p2_load_rows
+        monkeypatch.setattr(eng.lib, "tfem_p2_load_rows", lambda *a: calls.append(1) or inner(*a))
+        got[path] = eng.load(torch.tensor(fq_np)).cpu().double().numpy().reshape(-1)
+        assert len(calls) == (1 if path == "rows" else 0)
+        if path == "rows":
+            assert (int(eng.p2_plan()["layout"][18]) > 100) == (mesh_kind == "delaunay_morton")
+        monkeypatch.setattr(eng.lib, "tfem_p2_load_rows", inner)
+    local = orc.integrate_local(fq_np.reshape(-1, nq, 1, 1) * geo["v"], geo["dx"])
+    want = orc.assemble_linear(local, conn6, xy.shape[0]).reshape(-1).astype(np.float64)
+    assert scaled_error(got["rows"], want) <= tol
+    assert scaled_error(got["rows"], got["gather"]) <= (1e-13 if dtype == torch.float64 else 2e-5)
+    if dtype == torch.float64:  # every entry against the scale of its own row: the magnitudes of its terms
+        terms = orc.integrate_local(np.abs(fq_np.reshape(-1, nq, 1, 1) * geo["v"]), np.abs(geo["dx"]))
+        shares = np.zeros(xy.shape[0])
+        np.add.at(shares, conn6.reshape(-1), terms.reshape(-1))
+        assert (np.abs(got["rows"] - want) <= 1e-12 * np.maximum(shares, 1e-300)).all()
+
+
 def test_p2_row_plan_on_unstructured_meshes_and_its_fallback():
     """A Delaunay mesh with a numbering that has locality (Morton) runs the row kernels (its
     vertices with more than seven neighbours as long rows); the native scipy numbering of a

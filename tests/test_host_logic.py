@@ -14,7 +14,7 @@ from oracle import assembly_oracle as orc
 from plan_emulator import run_plan
 import ring_emulator
 from ring_emulator import run_ring_plan
-from p2rows_emulator import run_p2_plan
+from p2rows_emulator import run_p2_load_plan, run_p2_plan
 
 
 #: 2 pi^2 sin(pi x) sin(pi y) as the tracer compiles it (tests/test_assembly.py:75-77)
@@ -466,6 +466,22 @@ def test_p2_row_plan_is_a_valid_exact_cover(kind, form):
     local = orc.integrate_local(integrand, geo["dx"])
     want = orc.assemble_csr_values(local, slots.reshape(-1, 6, 6), colind.shape[0])
     assert scaled_error(vals, want) <= 1e-13
+    _check_p2_load_codes(plan, mesh, conn6, nv, nd)
+
+
+def _check_p2_load_codes(plan, mesh, conn6, nv, nd):
+    """The load vector walked from the plan's element codes (k_p2_load_rows, tests/p2rows_emulator.py):
+    every DoF written once, equal to the oracle's assembled P2 load vector -- with source values that
+    differ from point to point and from element to element, so a wrong element or local index shows."""
+    for order in (2, 4):
+        geo = orc.geometry(mesh["vertices"][mesh["triangles"]], 2, order)
+        nq = geo["dx"].shape[1]
+        fq = np.random.default_rng(5).uniform(-1.0, 2.0, size=(conn6.shape[0], nq))
+        f, writes = run_p2_load_plan(plan, mesh["vertices"], nv, nd, fq, order)
+        assert (writes == 1).all()
+        local = orc.integrate_local(fq.reshape(-1, nq, 1, 1) * geo["v"], geo["dx"])
+        want = orc.assemble_linear(local, conn6, nd).reshape(-1)
+        assert scaled_error(f, want) <= 1e-13
 
 
 def test_p2_row_plan_long_rows_on_delaunay_meshes_and_what_it_rejects():
@@ -497,6 +513,8 @@ def test_p2_row_plan_long_rows_on_delaunay_meshes_and_what_it_rejects():
             local = orc.integrate_local(integrand, geo["dx"])
             want = orc.assemble_csr_values(local, slots.reshape(-1, 6, 6), colind.shape[0])
             assert scaled_error(vals, want) <= 1e-13
+        assert plan["long_codes"].size >= 16
+        _check_p2_load_codes(plan, mesh, conn6, nv, nd)
     # a fan of 16 triangles around one vertex
     k = 16
     ang = np.linspace(0, 2 * np.pi, k, endpoint=False)

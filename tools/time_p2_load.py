@@ -35,6 +35,8 @@ program = (x * y + 1.0).program()
 fq = eng.source_values(program)
 print(f"P2, S(707) = {eng.n_elems} elements, {eng.n_dofs} DoFs, order {order} (Q = {eng.n_quad})")
 print(f"K (tfem_p2_assemble_rows)            {timed(lambda: eng.bilinear(1.0, 0.0)):8.1f} us")
-print(f"f from source values (load)          {timed(lambda: eng.load(fq)):8.1f} us")
-print(f"f from a source program              {timed(lambda: eng.load_source(program)):8.1f} us")
+for path in ("rows", "gather"):  # row form over the P2 plan / element vectors + gather
+    os.environ["TFEM_P2_LOAD"] = path
+    print(f"f from source values (load), {path:7s} {timed(lambda: eng.load(fq)):8.1f} us")
+    print(f"f from a source program, {path:7s}     {timed(lambda: eng.load_source(program)):8.1f} us")
 print(f"tfem_source_eval alone               {timed(lambda: eng.source_values(program)):8.1f} us")
