@@ -19,6 +19,7 @@
 // row records 8 B + halo vertex ids ~1 B + coordinates ~9.5 B (halo re-reads included) +
 // values 28.6 B = 47.6 B, against 48 B algorithmic: the 16-byte row records replace the
 // 24 bytes of connectivity the row's triangles take.
+#include <cmath>
 #include <cstdio>
 #include <mutex>
 #include <vector>
@@ -208,6 +209,26 @@ static int launch_rings(const RingLaunch &L) {
       a.lam[i][q] = T(tables.lam[q][i]);
       a.hw[q] = T(tables.hw[q]);
     }
+  if (src && tables.nq == 4) {
+    // the structure of the 4-point rule the QL = 4 instantiations use (RingArgs::qsym)
+    // (c0, a, b from the rule's literals; 1 - xi - eta of the reference's table is the same to an ulp)
+    const double c0 = tables.lam[0][1], aa = tables.lam[1][1], b = tables.lam[1][2], d = aa - b;
+    const int at[4] = {0, 1, 2, 0};
+    const double tol = sizeof(T) == 8 ? 1e-15 : 1e-6;  // the tables are rounded to the launch's real type
+    auto near = [tol](double x, double y) { return std::fabs(x - y) <= tol; };
+    bool ok = tables.hw[1] == tables.hw[2] && tables.hw[1] == tables.hw[3];
+    for (int i = 0; i < 3; ++i) {
+      ok = ok && near(tables.lam[0][i], c0);
+      for (int q = 1; q < 4; ++q) ok = ok && near(tables.lam[q][i], i == at[q] ? aa : b);
+    }
+    if (!ok) return fail(TFEM_ERR_UNSUPPORTED, "the 4-point rule is not the reference's order-3 rule");
+    a.qsym[0] = T(c0);
+    a.qsym[1] = T(b);
+    a.qsym[2] = T(d);
+    a.qsym[3] = T(c0) * T(tables.hw[0]);
+    a.qsym[4] = T(b) * T(tables.hw[1]);
+    a.qsym[5] = T(d) * T(tables.hw[1]);
+  }
   if (src) {
     if (z[20] == 0 || z[21] == 0)
       return fail(TFEM_ERR_UNSUPPORTED, "the ring plan carries no element vertex table (source programs)");

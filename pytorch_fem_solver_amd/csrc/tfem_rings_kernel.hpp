@@ -19,6 +19,11 @@
 // order anyway; parity is asserted at 1e-12 against the oracle).
 #pragma clang fp contract(fast)
 
+// developer switch: 0 = the general sum over the rule's points in the source-program launches' g
+#ifndef TFEM_SRC_QSYM
+#define TFEM_SRC_QSYM 1
+#endif
+
 namespace tfem {
 
 constexpr int kRingBlock = 256;             // lanes per workgroup = owned rows per tile
@@ -47,6 +52,11 @@ struct RingArgs {
   T hw[kMaxQuad];       // w_q / 2 (source programs: g_i = sum_q (f_q w_q / 2) l_i(q) needs this and `lam`
                         // only -- a second table of 3 Q doubles does not fit the scalar registers and
                         // came back from its spill lanes with two v_readlane per use)
+  // source programs, the 4-point rule (order 3: the centroid, weights (c0, c0, c0), and the three
+  // points with weights (b, b, b) + d on vertex 1, 2, 0; element_tri.py:99-107): [0..2] c0, b, d;
+  // [3..5] c0 w_0 / 2, b w_1 / 2, d w_1 / 2 of g_i = sum_q (f_q w_q / 2) l_i(q) (w_1 = w_2 = w_3):
+  // g_i = c0 w_0/2 f_0 + b w_1/2 (f_1 + f_2 + f_3) + d w_1/2 f_{q(i)}
+  T qsym[6];
   unsigned off_tverts;  // packed local vertex triples of the tiles' elements (source programs)
   // source programs: the launch walks positions [u_first, u_first + n_tiles) of the plan's chain
   // order (off_chain: position -> tile), a workgroup takes chain_len consecutive positions;
@@ -733,15 +743,24 @@ __global__ __launch_bounds__(kRingBlock, (SRC && SLOTS == 7 && QL <= 4) ? 4 : (S
         lds_xy(xyc, (code >> 10) & 0x3FFu, x1, y1);
         lds_xy(xyc, (code >> 20) & 0x3FFu, x2, y2);
         const T det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-        T fw[QL > 0 ? QL : 1];
+        if constexpr (QL == 4 && TFEM_SRC_QSYM) {
+          // the order-3 rule's structure (RingArgs::qsym): 7 operations instead of 16
+          const T *f4 = fv + j * 4;
+          const T base = src_fma<T>(a.qsym[3], f4[0], a.qsym[4] * ((f4[1] + f4[2]) + f4[3]));
+          add_share(code & 0x3FFu, acc, det * src_fma<T>(a.qsym[5], f4[3], base));
+          add_share((code >> 10) & 0x3FFu, acc, det * src_fma<T>(a.qsym[5], f4[1], base));
+          add_share((code >> 20) & 0x3FFu, acc, det * src_fma<T>(a.qsym[5], f4[2], base));
+        } else {
+          T fw[QL > 0 ? QL : 1];
 #pragma unroll
-        for (int q = 0; q < QL; ++q) fw[q] = fv[j * (QL > 0 ? QL : 1) + q] * a.hw[q];
+          for (int q = 0; q < QL; ++q) fw[q] = fv[j * (QL > 0 ? QL : 1) + q] * a.hw[q];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          T g = T(0);
+          for (int i = 0; i < 3; ++i) {
+            T g = T(0);
 #pragma unroll
-          for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
-          add_share((code >> (10 * i)) & 0x3FFu, acc, det * g);
+            for (int q = 0; q < QL; ++q) g = g + fw[q] * a.lam[i][q];
+            add_share((code >> (10 * i)) & 0x3FFu, acc, det * g);
+          }
         }
       }
     }

@@ -410,6 +410,10 @@ __device__ __forceinline__ void src_run_wide(const SrcLanes<T> &prog, const T *x
         // the LDS addresses are formed here, from the packed ids: formed once in front of the
         // program loop they cost nine registers the kernel does not have (they went to scratch:
         // +45 MB of writes per launch at 1e7 elements).  All reads are issued before the first use.
+        // (The points keep the reference's form l^T X, basis.py:90-91: the 4-point rule's structure --
+        // b S + d X_i -- would save nine operations per element, but sin(pi x) at the boundary x -> 1
+        // amplifies a last-bit difference of x_q by 1 / (1 - x) ~ 1e4, and the load vector's entries
+        // there left the 1e-12 entry-wise bound against the oracle: 2e-12 at 1e7 elements.)
         unsigned code[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
