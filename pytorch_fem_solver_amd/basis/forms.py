@@ -42,8 +42,11 @@ def _is_scalar(value):
         return False
     if isinstance(value, numbers.Real):
         return True
+    # 0-dim tensors on the CPU only: float() of a device scalar is a host synchronisation per
+    # integrate_* call (training loops), with the value baked into the program -- those take the
+    # torch path like any other tensor
     return isinstance(value, torch.Tensor) and value.dim() == 0 and not value.requires_grad \
-        and value.dtype.is_floating_point
+        and value.dtype.is_floating_point and value.device.type == "cpu"
 
 
 def _scalar(value):
@@ -633,7 +636,11 @@ def trace(function, basis, args, kwargs):
     SourceExpr when the result is inside the vocabulary, else the integrand as a real tensor
     (the symbols turned into tensors along the way).  A callable the proxy cannot serve at all
     (it assigns attributes on the basis, tests ``isinstance`` ...) is called on the real basis,
-    and remembered: the next call goes to the real basis directly."""
+    and remembered: the next call goes to the real basis directly.  That ONE time the callable
+    has run twice (up to the point where the proxy failed, then on the real basis): side effects
+    in front of that point -- random numbers drawn, counters -- happen twice on the first call.
+    ``x ** n`` for integer 2 <= n <= 8 becomes repeated multiplication in a source program
+    (torch calls pow): equal to rounding, not bit for bit."""
     refused = basis.__dict__.setdefault("_untraceable_callables", set())
     key = getattr(function, "__code__", None) or id(function)
     if key not in refused:

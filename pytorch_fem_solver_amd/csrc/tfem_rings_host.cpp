@@ -605,19 +605,59 @@ void chain_shares(double (&share)[4]) {
   }
 }
 
-// first position of every run (+ n_tiles): lengths proportional to the share of the run's quarter
+// first position of every run (+ n_tiles).  Whole tiles per run, so the lengths are the integers
+// that MINIMISE the longest run measured in its own workgroup's time: a workgroup of quarter q needs
+// 1 / share[q] per tile, the launch lasts max_w len_w / share_w.  T = the smallest such maximum with
+// sum_w floor(T share_w) >= n_tiles; what is over is taken from the runs closest to T.  For long runs
+// this is the proportional split; for the short runs of small meshes and of the shards of a strong
+// split (5 tiles per workgroup at 2.5e6 elements) it avoids the one tile more that a rounded share
+// gives some of the oldest workgroups: S(1118) 61.2 -> 56 us (profiles/r03_fused_launch_sizes.log).
 std::vector<int32_t> chain_runs(int64_t n_tiles, int64_t wgs) {
   double share[4];
   chain_shares(share);
-  std::vector<double> weight(static_cast<size_t>(wgs));
-  double total = 0;
-  for (int64_t w = 0; w < wgs; ++w) total += (weight[size_t(w)] = share[std::min<int64_t>(3, 4 * w / wgs)]);
-  std::vector<int32_t> first(size_t(wgs) + 1, 0);
-  double acc = 0;
-  for (int64_t w = 0; w < wgs; ++w) {
-    acc += weight[size_t(w)];
-    first[size_t(w) + 1] = int32_t(std::llround(double(n_tiles) * acc / total));
+  auto quarter = [&](int64_t w) { return int(std::min<int64_t>(3, 4 * w / wgs)); };
+  int64_t members[4] = {0, 0, 0, 0};
+  for (int64_t w = 0; w < wgs; ++w) members[quarter(w)]++;
+  // candidates for T: k / share[q]
+  std::vector<double> cand;
+  double sum_share = 0;
+  for (int q = 0; q < 4; ++q) sum_share += share[q] * double(members[q]);
+  const int64_t kmax = int64_t(double(n_tiles) / std::max(sum_share, 1e-300) * std::max({share[0], share[1], share[2], share[3]})) + 3;
+  for (int q = 0; q < 4; ++q)
+    for (int64_t k = 1; k <= kmax; ++k) cand.push_back(double(k) / share[q]);
+  std::sort(cand.begin(), cand.end());
+  int64_t len_q[4] = {0, 0, 0, 0};
+  for (double t : cand) {
+    int64_t total = 0;
+    for (int q = 0; q < 4; ++q) total += members[q] * (len_q[q] = int64_t(std::floor(t * share[q] * (1.0 + 1e-12))));
+    if (total >= n_tiles) break;
   }
+  std::vector<int64_t> len(static_cast<size_t>(wgs));
+  int64_t total = 0;
+  for (int64_t w = 0; w < wgs; ++w) total += (len[size_t(w)] = len_q[quarter(w)]);
+  // what is over: one tile less for runs of the quarter whose runs take longest, spread over the
+  // quarter (every other, every third ... run), then the next quarter
+  while (total > n_tiles) {
+    int worst = -1;
+    double worst_t = -1;
+    for (int q = 0; q < 4; ++q)
+      if (members[q] > 0 && len_q[q] > 0 && double(len_q[q]) / share[q] > worst_t) {
+        worst_t = double(len_q[q]) / share[q];
+        worst = q;
+      }
+    if (worst < 0) break;
+    const int64_t take = std::min<int64_t>(total - n_tiles, members[worst]);
+    int64_t first_w = 0;
+    while (quarter(first_w) != worst) ++first_w;
+    for (int64_t i = 0; i < take; ++i) {
+      const int64_t w = first_w + (i * members[worst]) / take;  // spread over the quarter
+      len[size_t(w)]--;
+    }
+    total -= take;
+    len_q[worst]--;
+  }
+  std::vector<int32_t> first(size_t(wgs) + 1, 0);
+  for (int64_t w = 0; w < wgs; ++w) first[size_t(w) + 1] = first[size_t(w)] + int32_t(len[size_t(w)]);
   first[size_t(wgs)] = int32_t(n_tiles);
   return first;
 }
