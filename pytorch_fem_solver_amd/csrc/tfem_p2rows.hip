@@ -144,11 +144,14 @@ __device__ __forceinline__ void p2_store_pieces(const T *stage, int total, int p
   }
 }
 
-// KIND 0: vertex rows, KIND 1: edge rows
-template <typename T, int KIND, bool MASS>
+// KIND 0: vertex rows, KIND 1: edge rows.  PASSES: a wave's rows go through its stage in that many
+// parts of 64 / PASSES rows (vertex rows: 11.3 KB of stage per wave in one part -- three workgroups
+// per CU; 2.8 KB in four parts -- six).
+template <typename T, int KIND, bool MASS, int PASSES = 1>
 __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
   constexpr int kMaxLen = KIND == 0 ? kP2VertexRowMax : kP2EdgeRowMax;
-  constexpr int kStageEntries = 64 * kMaxLen + 2;
+  constexpr int kStageEntries = (64 / PASSES) * kMaxLen + 2;
+  static_assert(PASSES == 1 || KIND == 0, "edge rows are staged in one part");
   extern __shared__ __attribute__((aligned(16))) unsigned char p2_smem[];
   T *xy = reinterpret_cast<T *>(p2_smem);  // [2 * lds_vert]
   T *stage = xy + 2 * a.lds_vert;          // [waves][kStageEntries]
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
   __syncthreads();
 
   T *my_stage = stage + wave * kStageEntries;
-  constexpr int kSpare = 64 * kMaxLen;
+  constexpr int kSpare = (64 / PASSES) * kMaxLen;
   int len, pre;
   if constexpr (KIND == 0) {
     // ---- vertex row: the fan, as in tfem_rings.hip ----------------------------------------
@@ -273,20 +276,47 @@ __global__ __launch_bounds__(kP2Block) void k_p2_rows(const P2RowArgs<T> a) {
     const bool is_long = has_row && k == 0 && (w[3] >> 31) != 0u;
     const int true_len = is_long ? int(w[3] & 0x7FFFFFFFu) : len;
     const bool any_long = __ballot(is_long) != 0ull;
+    if constexpr (PASSES == 1) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      my_stage[i < k ? pre + field(i) : kSpare] = vcol[i];
-      my_stage[i < k ? pre + field(7 + i) : kSpare] = ecol[i];
-      my_stage[(i < k && flag_of(i)) ? pre + field(14 + i) : kSpare] = ocol[i];
-    }
-    my_stage[k > 0 ? pre + int(w[2] >> 27) : kSpare] = diag;
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    __builtin_amdgcn_wave_barrier();
-    if (!any_long) {
-      p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+      for (int i = 0; i < 7; ++i) {
+        my_stage[i < k ? pre + field(i) : kSpare] = vcol[i];
+        my_stage[i < k ? pre + field(7 + i) : kSpare] = ecol[i];
+        my_stage[(i < k && flag_of(i)) ? pre + field(14 + i) : kSpare] = ocol[i];
+      }
+      my_stage[k > 0 ? pre + int(w[2] >> 27) : kSpare] = diag;
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      __builtin_amdgcn_wave_barrier();
+      if (!any_long) {
+        p2_store<T, kMaxLen>(my_stage, total, rs0, r_vals);
+      } else {
+        const int csr = rs0 + wave_inclusive_scan(true_len) - true_len;
+        p2_store_pieces<T>(my_stage, total, pre, csr, is_long, r_vals);
+      }
     } else {
-      const int csr = rs0 + wave_inclusive_scan(true_len) - true_len;
-      p2_store_pieces<T>(my_stage, total, pre, csr, is_long, r_vals);
+      constexpr int kPart = 64 / PASSES;  // rows per part
+      const int csr = any_long ? rs0 + wave_inclusive_scan(true_len) - true_len : 0;
+      int base = 0;  // entries in front of the part's first row
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const bool mine = (lane / kPart) == pass;
+        const int upto = __builtin_amdgcn_readlane(incl, kPart * (pass + 1) - 1);
+        const int count = upto - base;
+        const int at = pre - base;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          my_stage[(mine && i < k) ? at + field(i) : kSpare] = vcol[i];
+          my_stage[(mine && i < k) ? at + field(7 + i) : kSpare] = ecol[i];
+          my_stage[(mine && i < k && flag_of(i)) ? at + field(14 + i) : kSpare] = ocol[i];
+        }
+        my_stage[(mine && k > 0) ? at + int(w[2] >> 27) : kSpare] = diag;
+        __builtin_amdgcn_wave_barrier();
+        if (!any_long)
+          p2_store<T, (kPart * kMaxLen + 63) / 64>(my_stage, count, rs0 + base, r_vals);
+        else
+          p2_store_pieces<T>(my_stage, count, at, csr, is_long, r_vals, kPart * pass, kPart * pass + kPart);
+        __builtin_amdgcn_wave_barrier();
+        base = upto;
+      }
     }
   } else {
     // ---- edge row: one or two triangles, each in its own stored frame ------------------------
@@ -824,11 +854,25 @@ static int launch_p2_rows(const void *coords, int quad_order, double alpha, doub
     a.lds_vert = (int(z[4 + kind]) + 1) & ~1;
     fill_tables(kind, a.ca, a.cb, a.cd, a.cm);
     const int max_len = kind == 0 ? kP2VertexRowMax : kP2EdgeRowMax;
-    const size_t lds = size_t(2 * a.lds_vert) * sizeof(T) + size_t(kP2Waves) * size_t(64 * max_len + 2) * sizeof(T);
-    void *kernel = kind == 0 ? (mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true>)
-                                     : reinterpret_cast<void *>(k_p2_rows<T, 0, false>))
-                             : (mass ? reinterpret_cast<void *>(k_p2_rows<T, 1, true>)
-                                     : reinterpret_cast<void *>(k_p2_rows<T, 1, false>));
+    // vertex rows: the wave's stage in parts (developer switch TFEM_P2_PASSES=2|4) -- more workgroups
+    // per CU (3 -> 5 -> 6) and SLOWER: S(707) 44.7-45.2 us in one part, 46.0-46.2 in two, 48.7-49.4 in
+    // four (profiles/r03_p2_stage_passes.log): the launch is not short of waves, it is at the rate of
+    // the bytes it moves
+    int passes = 1;
+    if (const char *v = std::getenv("TFEM_P2_PASSES")) {
+      const int p = std::atoi(v);
+      if (kind == 0 && (p == 1 || p == 2 || p == 4)) passes = p;
+    }
+    const size_t lds = size_t(2 * a.lds_vert) * sizeof(T) + size_t(kP2Waves) * size_t((64 / passes) * max_len + 2) * sizeof(T);
+    void *kernel;
+    if (kind == 1)
+      kernel = mass ? reinterpret_cast<void *>(k_p2_rows<T, 1, true>) : reinterpret_cast<void *>(k_p2_rows<T, 1, false>);
+    else if (passes == 4)
+      kernel = mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true, 4>) : reinterpret_cast<void *>(k_p2_rows<T, 0, false, 4>);
+    else if (passes == 2)
+      kernel = mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true, 2>) : reinterpret_cast<void *>(k_p2_rows<T, 0, false, 2>);
+    else
+      kernel = mass ? reinterpret_cast<void *>(k_p2_rows<T, 0, true>) : reinterpret_cast<void *>(k_p2_rows<T, 0, false>);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
       if (e != hipSuccess) return fail(TFEM_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
