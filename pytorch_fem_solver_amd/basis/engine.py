@@ -762,6 +762,18 @@ class AssemblyEngine:
         except KeyError:
             raise ValueError(f"tiles: {which!r} is not 'priority', 'rest' or 'all'") from None
 
+    def _resident_source_workgroups(self):
+        """Workgroups of a source-program ring launch that are resident at once on this device: four
+        per CU (128 VGPRs, < 40 KB of LDS: csrc/tfem_rings.hip), on the CUs the launches may use."""
+        cus = 256
+        if self.device.type == "cuda":
+            cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        try:
+            reserve = max(0, int(os.environ.get("TFEM_RINGS_RESERVE_CUS", "0") or 0))
+        except ValueError:
+            reserve = 0
+        return (max(8, cus - 8 * reserve) * 4 // 8) * 8
+
     def ring_plan(self):
         """Device copy of the ring plan (row form of the P1 stiffness/mass kernel), or None
         when this basis cannot use it (P2, fractures, fans that have no ring form)."""
@@ -770,6 +782,13 @@ class AssemblyEngine:
             if self.kernel in ("auto", "rings") and self._p1_plan_eligible():
                 self.csr_structure()
                 rowptr, colind = self._csr_host
+                # one run of the chain order per RESIDENT workgroup of a source-program launch: four per
+                # CU the launches may use (TFEM_RINGS_RESERVE_CUS: CUs per XCD a sharded step leaves to
+                # the interface exchange).  A launch with fewer workgroups than the plan has runs still
+                # writes the same values, but some workgroups then walk two runs one after the other.
+                wgs_given = os.environ.get("TFEM_RING_WGS")
+                if wgs_given is None:
+                    os.environ["TFEM_RING_WGS"] = str(self._resident_source_workgroups())
                 try:
                     plan = ring_plan_host(
                         self._conn_host_np(), self.n_dofs, self._coords_host_np(), rowptr, colind,
@@ -778,6 +797,8 @@ class AssemblyEngine:
                 except NotImplementedError:
                     plan = None
                 finally:
+                    if wgs_given is None:
+                        os.environ.pop("TFEM_RING_WGS", None)
                     if self._pattern is not None:
                         self._pattern.release()
                         self._pattern = None
