@@ -507,6 +507,8 @@ def main():
             barrier()
         step_mode = sharded.mode
     run(args.warmup)
+    if sharded is not None:
+        sharded.align()  # (untimed) the timed steps start where a replay can: replays first, eager remainder last
     barrier()
 
     # live launch duration: HIP events on the launch stream around the WHOLE timed region (the
@@ -532,8 +534,15 @@ def main():
     else:
         out = run(args.steps)
         host_s = time.perf_counter() - t0  # the host's share: enqueueing (replaying) the steps
-    barrier()
+    # this rank's K steps are complete -- every exchange of theirs included, which no rank finishes
+    # before all ranks have contributed -- when its streams have drained; the slowest rank's time is
+    # the job's (MAX below).  The closing barrier follows OUTSIDE the clock: its own latency (a
+    # collective of tens of microseconds) is not part of K steps of a few hundred.
+    if sharded is not None:
+        sharded.sync()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     if distributed:
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

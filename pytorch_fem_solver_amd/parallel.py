@@ -386,6 +386,15 @@ class ShardedSteps:
             n -= 1
         return self.pairs[(self.counter - 1) % self.depth]
 
+    def align(self):
+        """Eager steps until the next step writes pair 0 again -- where a replay can start.  For
+        callers that time a run of steps: with the replays in FRONT, the host's time for the eager
+        steps of the remainder hides behind the device's queue instead of starving it."""
+        extra = (-self.counter) % self.depth
+        if extra:
+            self.run(extra)
+        return extra
+
     def sync(self):
         """Host wait for everything enqueued so far (both streams)."""
         self.main.synchronize()

@@ -103,6 +103,8 @@ def main():
         if args.stepper.startswith("graph"):
             assert steps.capture(6), steps.capture_error
         out = steps.run(6 + 6 + 2)  # replays and eager steps, in this order and mixed
+        assert steps.align() == (-(4 + 14)) % 3 and steps.counter % 3 == 0  # bench.py: timed steps start at a replay
+        out = steps.run(6 + 1)
         steps.sync()
         mode = steps.mode
         for pair in steps.pairs:  # every pair holds the same complete result (K bit for bit)
