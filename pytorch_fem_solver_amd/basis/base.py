@@ -12,9 +12,11 @@ from __future__ import annotations
 
 import abc
 import os
+import warnings
 
 import torch
 
+from .. import _native
 from ..sparse import CSRMatrix
 from . import forms
 
@@ -208,7 +210,7 @@ class AbstractBasis(abc.ABC):
         if isinstance(a_expr, forms.BilinearExpr) and isinstance(l_expr, forms.LinearExpr) and l_expr.flux is None:
             coefficient = l_expr.coefficient
             if isinstance(coefficient, forms.SourceExpr):
-                program = coefficient.program() if self._engine.supports_source() else None
+                program = self._source_program(coefficient)
                 if program is not None:
                     fused = self._engine.assemble_system(a_expr.alpha, a_expr.beta, source=program)
                 else:
@@ -222,6 +224,22 @@ class AbstractBasis(abc.ABC):
                     self.integrate_linear_form(linear, *args, **kwargs))
         vals, f = fused
         return self._finish_matrix(vals, layout), self._engine._home(f).reshape(-1, 1)
+
+    def _source_program(self, coefficient):
+        """The source program of a traced coefficient, or None -- said ONCE per basis when it is the
+        program's limits that send the expression to torch (include/tfem_assembly.h: 32 operations,
+        a stack of 4): the results are the same, the step then reads 8 Q bytes per element more."""
+        if not self._engine.supports_source():
+            return None
+        program = coefficient.program()
+        if program is None and not self.__dict__.get("_warned_source_limits"):
+            self.__dict__["_warned_source_limits"] = True
+            warnings.warn(
+                "the source expression does not fit a source program (more than "
+                f"{_native.SOURCE_MAX_OPS} operations or {_native.SOURCE_STACK} values at a time): torch evaluates it at the "
+                "cached integration points and the assembly launch reads the values from memory",
+                RuntimeWarning, stacklevel=3)
+        return program
 
     def _finish_matrix(self, vals, layout):
         matrix = self._engine.wrap_csr(vals)
@@ -241,7 +259,7 @@ class AbstractBasis(abc.ABC):
             coefficient = expr.coefficient
             if isinstance(coefficient, forms.SourceExpr):
                 # f(x, y) recorded by the tracer: evaluated inside the assembly launch
-                program = coefficient.program() if self._engine.supports_source() else None
+                program = self._source_program(coefficient)
                 if program is not None:
                     return self._engine._home(self._engine.load_source(program)).reshape(-1, 1)
                 coefficient = coefficient.materialize()
