@@ -1122,6 +1122,13 @@ class AssemblyEngine:
     def _rings_take_source(self):
         if self.kernel == "tiles" or not self._use_rings():
             return False
+        # TFEM_DETERMINISTIC=1: load vectors bit for bit the same from launch to launch.  The launch
+        # that evaluates the source itself sums a vertex's element shares in LDS in the order the waves
+        # reach them (reproducible to rounding, <= 1e-15 relative); with this switch the source goes
+        # to memory first (tfem_source_eval) and the row-form launch that reads source values sums
+        # every row's shares in fan order -- two launches, ~0.30 instead of 0.16 ms at 1e7 elements.
+        if os.environ.get("TFEM_DETERMINISTIC", "0") not in ("", "0"):
+            return False
         rings = self.ring_plan()
         return bool(rings["elems_staged"] and rings["has_tverts"])
 

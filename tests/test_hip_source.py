@@ -269,6 +269,30 @@ def test_fused_launch_writes_the_same_matrix_bits_as_the_matrix_only_launch(beta
                 torch.set_default_dtype(torch.float64)
 
 
+def test_deterministic_switch_gives_the_load_vector_bit_for_bit_from_launch_to_launch(monkeypatch):
+    """TFEM_DETERMINISTIC=1: the source is evaluated into memory and the row-form launch sums every
+    row's shares in fan order -- K and f bitwise equal from launch to launch (the launch that
+    evaluates the source itself adds the shares in LDS in arrival order: equal to rounding only);
+    same vector as the default route to rounding."""
+    from pytorch_fem_solver_amd import meshgen
+
+    mesh_np = meshgen.unit_square(230, 0.25, 1)
+    basis = tf().Basis(tf().MeshTri(mesh_np), tf().ElementTri(1, 3))
+    eng = basis._engine
+    _, program = _traced(basis, FIELDS["sin_sin"])
+    assert eng._rings_take_source()
+    _, f_default = eng.assemble_system(1.0, 0.5, source=program)
+    monkeypatch.setenv("TFEM_DETERMINISTIC", "1")
+    assert not eng._rings_take_source()
+    runs = [eng.assemble_system(1.0, 0.5, source=program) for _ in range(6)]
+    for vals, f in runs[1:]:
+        assert torch.equal(vals, runs[0][0]) and torch.equal(f, runs[0][1])
+    alone = [basis.integrate_linear_form(load).reshape(-1) for _ in range(3)]  # the load-vector-only launch
+    assert torch.equal(alone[0], alone[1]) and torch.equal(alone[0], alone[2])
+    assert scaled_error(alone[0].cpu(), runs[0][1].reshape(-1).cpu()) <= 1e-14
+    assert scaled_error(runs[0][1].cpu(), f_default.cpu()) <= 1e-14
+
+
 def test_plan_has_one_run_per_resident_workgroup_also_when_the_launches_leave_cus_free(monkeypatch):
     """A sharded step launches with TFEM_RINGS_RESERVE_CUS=1 (one CU per XCD stays free for the
     interface exchange): the engine then asks the plan for one run per workgroup of THAT launch --
