@@ -66,7 +66,10 @@ def parse():
                    "the next step's launch")
     p.add_argument("--step-mode", choices=("auto", "graph", "eager"), default="auto",
                    help="N > 1: auto = the steps recorded into HIP graphs over RCCL, eager over gloo")
-    p.add_argument("--graph-steps", type=int, default=6, help="steps per HIP graph (a multiple of 3)")
+    p.add_argument("--graph-steps", type=int, default=24,
+                   help="steps per HIP graph (a multiple of 3; capped by --steps).  A replay ends with an exchange nothing "
+                        "overlaps and a gap to the next replay, ~24 us in all: 41.8 us per step in graphs of 6, 38.3 in "
+                        "graphs of 24 at 1.25e6 elements per rank (profiles/r03_step_host_overhead.log)")
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the short measurements of the other configurations (P2; Delaunay meshes)")
     p.add_argument("--delaunay-points", type=int, default=1_000_000,
@@ -502,8 +505,9 @@ def main():
     step_mode = "single launch per step"
     if sharded is not None:
         want_graph = args.step_mode == "graph" or (args.step_mode == "auto" and args.backend == "nccl")
-        if want_graph and sharded.capture(args.graph_steps):
-            run(2 * args.graph_steps)  # the replays themselves, once, before anything is timed
+        graph_steps = (min(args.graph_steps, args.steps) // 3) * 3  # whole replays inside the timed steps
+        if want_graph and graph_steps >= 3 and sharded.capture(graph_steps):
+            run(2 * graph_steps)  # the replays themselves, once, before anything is timed
             barrier()
         step_mode = sharded.mode
     run(args.warmup)

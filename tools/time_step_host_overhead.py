@@ -3,7 +3,7 @@ ONE rank over RCCL and a small mesh -- the launches are short, so what the wall 
 step is the host: Python + ctypes + stream bookkeeping + the collective's enqueue for the eager
 steps, a fraction of one graph launch for the steps recorded into HIP graphs.
 
-    python tools/time_step_host_overhead.py [n] [steps per graph]
+    python tools/time_step_host_overhead.py [n] [steps per graph] [pairs]
 """
 import math
 import os
@@ -27,6 +27,7 @@ torch.set_default_dtype(torch.float64)
 torch.set_default_device("cuda")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 graph_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 3  # rotating (vals, f) pairs
 mesh_np = meshgen.structured_rectangle(n, n, 0.0, 1.0, 1.0, 2.0, jitter=0.25, seed=0)
 basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(1, 3))
 eng = basis._engine
@@ -66,7 +67,7 @@ for first in (False, True):
         basis = tf.Basis(tf.MeshTri(triangulation=mesh_np), tf.ElementTri(1, 3))
         eng = basis._engine
         eng.set_priority_vertices(ex.shared_vertices(nv))
-    steps = parallel.ShardedSteps(eng, ex, 1.0, 0.0, source=program, depth=3, interface_first=first)
+    steps = parallel.ShardedSteps(eng, ex, 1.0, 0.0, source=program, depth=depth, interface_first=first)
     what = "interface tiles first (two launches)" if first else "one launch per step"
     timed(steps, f"eager, {what}")
     ok = steps.capture(graph_steps)
