@@ -522,6 +522,12 @@ int tfem_interface_pack(const void *vals, const void *f, int real_bytes, const i
 int tfem_interface_unpack(void *vals, void *f, int real_bytes, const int64_t *k_idx,
                           const int64_t *k_pos, int64_t nk, const int64_t *f_idx,
                           const int64_t *f_pos, int64_t nf, const void *buf, void *stream);
+/* pack in ONE launch, for the repeated step of a sharded run (the exchange chain -- zero, pack,
+ * all-reduce, unpack, each behind the other -- is what bounds such a step at 1e6 elements per rank):
+ * src (nbuf, int64 device array): >= 0 an entry of vals, <= -2 entry -src - 2 of f, -1 a position
+ * other ranks own (written as zero).  buf[p] for every p < nbuf. */
+int tfem_interface_pack_dense(const void *vals, const void *f, int real_bytes, const int64_t *src,
+                              int64_t nbuf, void *buf, void *stream);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
          c_void_p, c_void_p],
     ),
+    "tfem_interface_pack_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "tfem_source_validate": (c_int, [c_void_p]),
     "tfem_source_eval": (
         c_int,

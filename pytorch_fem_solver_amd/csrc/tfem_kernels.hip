@@ -721,6 +721,16 @@ __global__ void k_interface_pack(const T *vals, const T *f, const int64_t *k_idx
   }
 }
 
+// The same pack in ONE launch (no memset in front): one thread per buffer position, src[p] >= 0: an
+// entry of vals, src[p] <= -2: entry -src[p] - 2 of f, -1: a position other ranks own (zero).
+template <typename T>
+__global__ void k_interface_pack_dense(const T *vals, const T *f, const int64_t *src, int64_t nbuf, T *buf) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= nbuf) return;
+  const int64_t s = src[p];
+  buf[p] = s >= 0 ? vals[s] : (s <= -2 ? f[-s - 2] : T(0));
+}
+
 template <typename T>
 __global__ void k_interface_unpack(T *vals, T *f, const int64_t *k_idx, const int64_t *k_pos,
                                    int64_t nk, const int64_t *f_idx, const int64_t *f_pos, int64_t nf,
@@ -978,6 +988,25 @@ int tfem_interface_pack(const void *vals, const void *f, int real_bytes, const i
     hipLaunchKernelGGL(k_interface_pack<float>, dim3(blocks_for(nk + nf)), dim3(kBlock), 0, s,
                        static_cast<const float *>(vals), static_cast<const float *>(f), k_idx, k_pos,
                        nk, f_idx, f_pos, nf, static_cast<float *>(buf));
+  TFEM_HIP_CHECK(hipGetLastError());
+  return TFEM_OK;
+}
+
+int tfem_interface_pack_dense(const void *vals, const void *f, int real_bytes, const int64_t *src,
+                              int64_t nbuf, void *buf, void *stream) {
+  if (real_bytes != 4 && real_bytes != 8) return fail(TFEM_ERR_INVALID_ARGUMENT, "real_bytes must be 4 or 8");
+  if (nbuf < 0) return fail(TFEM_ERR_INVALID_ARGUMENT, "negative size");
+  if (nbuf == 0) return TFEM_OK;
+  if (!vals || !f || !src || !buf) return fail(TFEM_ERR_INVALID_ARGUMENT, "NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (real_bytes == 8)
+    hipLaunchKernelGGL(k_interface_pack_dense<double>, dim3(blocks_for(nbuf)), dim3(kBlock), 0, s,
+                       static_cast<const double *>(vals), static_cast<const double *>(f), src, nbuf,
+                       static_cast<double *>(buf));
+  else
+    hipLaunchKernelGGL(k_interface_pack_dense<float>, dim3(blocks_for(nbuf)), dim3(kBlock), 0, s,
+                       static_cast<const float *>(vals), static_cast<const float *>(f), src, nbuf,
+                       static_cast<float *>(buf));
   TFEM_HIP_CHECK(hipGetLastError());
   return TFEM_OK;
 }

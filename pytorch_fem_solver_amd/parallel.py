@@ -13,6 +13,8 @@ The exchange is backend-agnostic (``nccl`` = RCCL on GPUs, ``gloo`` in the CPU t
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -146,7 +148,20 @@ class InterfaceExchange:
                     _native.check(status)
             return call
 
-        return run(lib.tfem_interface_pack, head + (buf.numel(),)), run(lib.tfem_interface_unpack, head)
+        unpack = run(lib.tfem_interface_unpack, head)
+        if vals is not None and flat_f is not None and os.environ.get("TFEM_INTERFACE_PACK", "dense") == "dense":
+            # pack in ONE launch (no memset in front): the exchange chain of a step -- pack, all-reduce,
+            # unpack, each behind the other -- bounds the step at ~1e6 elements per rank
+            if getattr(self, "_src", None) is None:
+                src = torch.full((buf.numel(),), -1, dtype=torch.int64, device=device)
+                src[self.k_pos] = self.k_idx
+                src[self.f_pos] = -self.f_idx - 2
+                self._src = src
+            dense = (_native.ptr(vals), _native.ptr(flat_f), buf.element_size(), _native.ptr(self._src),
+                     buf.numel(), _native.ptr(buf))
+            keep = keep + (self._src,)
+            return run(lib.tfem_interface_pack_dense, dense), unpack
+        return run(lib.tfem_interface_pack, head + (buf.numel(),)), unpack
 
     def pack(self, vals=None, f=None):
         """Zero the interface buffer and copy this rank's shared entries into it."""

@@ -1060,6 +1060,37 @@ def test_csr_spmv_and_cg_solve_against_the_dense_reference_solve():
     assert scaled_error(K2.matvec(y).cpu(), (K2.to_dense() @ y).cpu()) <= 1e-14
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_interface_pack_in_one_launch_equals_zero_fill_plus_pack(dtype, monkeypatch):
+    """tfem_interface_pack_dense (what the prepared steps of a sharded run enqueue: one launch) writes
+    the buffer tfem_interface_pack (memset + scatter) writes: shared entries of vals and f at their
+    positions, zeros at the positions other ranks own -- also over what a previous all-reduce left."""
+    from pytorch_fem_solver_amd import parallel
+
+    rng = np.random.default_rng(3)
+    nnz, nv, n_matrix, n_vector = 5000, 700, 700, 200
+    nbuf = n_matrix + n_vector  # matrix entries first, then vector entries
+    k_pos, f_pos = rng.permutation(n_matrix)[:450], rng.permutation(n_vector)[:150]
+    k_idx, f_idx = rng.permutation(nnz)[:450], rng.permutation(nv)[:150]
+    ex = parallel.InterfaceExchange(k_idx, k_pos, f_idx, f_pos, n_matrix, n_vector, torch.device("cuda"), dtype)
+    vals = torch.rand(nnz, dtype=dtype, device="cuda")
+    f = torch.rand(nv, dtype=dtype, device="cuda")
+    got = {}
+    for mode in ("dense", "scatter"):
+        monkeypatch.setenv("TFEM_INTERFACE_PACK", mode)
+        ex._src = None
+        pack, unpack = ex.prepared(vals, f)
+        ex.buffer.fill_(float("nan"))  # whatever was there before
+        pack()
+        torch.cuda.synchronize()
+        got[mode] = ex.buffer.clone()
+    assert torch.equal(got["dense"], got["scatter"])
+    want = torch.zeros(nbuf, dtype=dtype, device="cuda")
+    want[torch.as_tensor(k_pos, device="cuda")] = vals[torch.as_tensor(k_idx, device="cuda")]
+    want[n_matrix + torch.as_tensor(f_pos, device="cuda")] = f[torch.as_tensor(f_idx, device="cuda")]
+    assert torch.equal(got["dense"], want)
+
+
 @pytest.mark.parametrize("order_kind", ["morton", "native"])
 def test_partitioned_assembly_with_interface_sum_equals_the_global_operator(order_kind):
     """BASELINE config 4 (general element-range partition) with the device path on every

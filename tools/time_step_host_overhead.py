@@ -3,7 +3,7 @@ ONE rank over RCCL and a small mesh -- the launches are short, so what the wall 
 step is the host: Python + ctypes + stream bookkeeping + the collective's enqueue for the eager
 steps, a fraction of one graph launch for the steps recorded into HIP graphs.
 
-    python tools/time_step_host_overhead.py [n] [steps per graph] [pairs]
+    python tools/time_step_host_overhead.py [n] [steps per graph] [pairs] [tiny]
 """
 import math
 import os
@@ -38,6 +38,8 @@ nnz = int(eng.csr_structure()[1].shape[0])
 rows = np.concatenate([np.arange(n + 1), nv - 1 - np.arange(n + 1)])
 rowptr = eng.csr_structure()[0].cpu().numpy()
 k_idx = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in rows])
+if len(sys.argv) > 4 and sys.argv[4] == "tiny":  # an exchange of one entry: what the launch chain alone costs in a graph
+    k_idx, rows = k_idx[:1], rows[:1]
 ex = parallel.InterfaceExchange(k_idx, np.arange(k_idx.size), rows, np.arange(rows.size), k_idx.size, rows.size,
                                 eng.device, torch.float64)
 
